@@ -1,0 +1,86 @@
+"""ctypes loader for libdvsraster.so — mirrors include/dvs_raster.h and include/dvs_scene.h 1:1."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdvsraster.so")
+
+
+class DvsError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C divshot_amd/csrc` (or __graft_entry__.build()). "
+        "divshot_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+class Splats(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("sh0", C.c_void_p), ("shN", C.c_void_p), ("opacity", C.c_void_p),
+                ("scale", C.c_void_p), ("rot", C.c_void_p), ("n", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("focal_x", C.c_float), ("focal_y", C.c_float), ("campos", C.c_float * 3), ("width", C.c_int32),
+                ("height", C.c_int32), ("bg", C.c_float * 3)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("sh_degree", C.c_int32), ("antialias", C.c_int32), ("absgrad", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class FwdState(C.Structure):
+    _fields_ = [("radii", C.c_void_p), ("mean2d", C.c_void_p), ("depth", C.c_void_p), ("conic_opacity", C.c_void_p),
+                ("rgb", C.c_void_p), ("flags", C.c_void_p), ("tiles_touched", C.c_void_p), ("sorted_tile", C.c_void_p),
+                ("sorted_splat", C.c_void_p), ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p),
+                ("num_rendered", C.c_uint64), ("n", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("_pad", C.c_int32)]
+
+
+class SplatGrads(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("sh0", C.c_void_p), ("shN", C.c_void_p), ("opacity", C.c_void_p),
+                ("scale", C.c_void_p), ("rot", C.c_void_p), ("absgrad2d", C.c_void_p), ("mean2d", C.c_void_p)]
+
+
+class SceneSpec(C.Structure):
+    _fields_ = [("n", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sh_degree", C.c_int32),
+                ("n_cams", C.c_int32), ("seed", C.c_uint64), ("fov_x_deg", C.c_float), ("scale_log_offset", C.c_float)]
+
+
+# every symbol include/*.h declares (tests/test_abi.py checks this list against the headers)
+_PROTOS = {
+    "dvs_create": (C.c_void_p, [C.c_int, C.c_size_t, C.c_int, C.c_int]),
+    "dvs_destroy": (None, [C.c_void_p]),
+    "dvs_raster_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
+                                     C.c_void_p, C.POINTER(FwdState), C.POINTER(C.c_uint64)]),
+    "dvs_raster_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
+                                      C.c_void_p, C.POINTER(SplatGrads)]),
+    "dvs_sort_pairs_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
+    "dvs_export_sorted_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dvs_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_get_stage_timing": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float))]),
+    "dvs_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dvs_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dvs_device_malloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "dvs_device_free": (None, [C.c_void_p, C.c_void_p]),
+    "dvs_last_error": (C.c_char_p, []),
+    "dvs_version": (C.c_char_p, []),
+    "dvs_synth_splats": (C.c_int, [C.POINTER(SceneSpec)] + [C.c_void_p] * 6),
+    "dvs_synth_camera": (C.c_int, [C.POINTER(SceneSpec), C.c_int, C.POINTER(Camera)]),
+    "dvs_synth_target": (C.c_int, [C.POINTER(SceneSpec), C.c_int, C.c_void_p]),
+    "dvs_make_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(Camera)]),
+}
+for _name, (_res, _args) in _PROTOS.items():
+    _f = getattr(lib, _name)          # AttributeError here = the .so does not export a declared symbol
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(status, what="dvs call"):
+    if status != 0:
+        raise DvsError(f"{what} failed with status {status}: {lib.dvs_last_error().decode()}")

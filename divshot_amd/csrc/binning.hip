@@ -1,0 +1,307 @@
+// binning.hip — A3 tile-offset scan, A4 duplicate-with-keys, A5 radix sort, A6 tile ranges (gfx950).
+//
+// The (tileID|depth) order is produced by an LSD radix sort whose low 32 key bits (the depth) are
+// sorted BEFORE duplication: every instance of a splat carries the same depth bits, so the four
+// depth passes run over the N splats instead of the T instances, instances are then emitted in
+// depth order, and only the tile-id bits (ceil(log2 tiles) of them) are sorted over T.  The result
+// is bit-identical to a stable sort of ((tile << 32) | depth_bits) over the instance list emitted in
+// splat order (proof in DESIGN.md §4), at about a third of the HBM traffic.
+//
+// Reference anchors: key idea gsplat_viewz_cs.hlsl:250-253, sortable float gaussian_common.hlsl:115-120,
+// the viewer's own 8-bit-digit LSD sort renderer/gpu_sort.cpp:16-25,54-91 (32-bit keys, Vulkan; not reused).
+//
+// Wave64 idioms: digits are ranked with 8 ballots + mbcnt (a 64-wide multisplit), per-wave digit
+// counters live in LDS, no LDS atomics on the hot path.
+#include "dvs_device.h"
+#include "dvs_kernels.h"
+
+#define SORT_BLOCK 256
+#define SORT_WAVES (SORT_BLOCK / 64)
+#define SORT_ITEMS 8
+#define SORT_PART (SORT_BLOCK * SORT_ITEMS)   // keys per workgroup
+#define RADIX 256
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// peers = lanes of this wave holding the same 8-bit digit (invalid lanes never match valid ones)
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return valid ? peers : 0ull;
+}
+
+// block-wide exclusive scan of one uint32 per thread (256 threads); tmp = LDS[SORT_WAVES+1]
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) { const uint32_t t = tmp[w]; if ((uint32_t)w < wave) wbase += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return wbase + inc - v;
+}
+
+// ---- A5: one LSD pass = histogram, row scan, scatter -----------------------------------------------
+// wave w of block b owns the contiguous items [b*PART + w*512, +512), read in 8 rounds of 64.
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t* __restrict__ hist, uint32_t num_blocks) {
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX];
+    for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t wbase = (uint64_t)blockIdx.x * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = valid ? ((keys[idx] >> shift) & 0xFFu) : 0u;
+        const uint64_t peers = match_digit(d, valid);
+        if (valid) {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            if (below == 0) cnt[wave][d] += (uint32_t)__popcll(peers);
+        }
+    }
+    __syncthreads();
+    const uint32_t d = threadIdx.x;
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) s += cnt[w][d];
+    hist[(uint64_t)d * num_blocks + blockIdx.x] = s;
+}
+
+// one workgroup per digit: exclusive scan of its row of per-block counts, row total -> totals[d]
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_rowscan(uint32_t* __restrict__ hist, uint32_t num_blocks, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    uint32_t* row = hist + (uint64_t)blockIdx.x * num_blocks;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < num_blocks; base += SORT_BLOCK) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = idx < num_blocks ? row[idx] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, tmp, &tot);
+        if (idx < num_blocks) row[idx] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+               uint32_t* __restrict__ vals_out, uint64_t n, int shift, const uint32_t* __restrict__ hist,
+               const uint32_t* __restrict__ totals, uint32_t num_blocks) {
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX];     // per-wave digit counts, then per-wave destination bases
+    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t wbase = (uint64_t)blockIdx.x * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[idx] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[r] >> shift) & 0xFFu;
+        const uint64_t peers = match_digit(d, valid);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        uint32_t prev = 0;
+        if (valid) {
+            prev = cnt[wave][d];                                   // in-order LDS: all peers read before the leader writes
+            if (below == 0) cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+        }
+        rank[r] = prev + below;
+    }
+    __syncthreads();
+    {
+        // thread d: global base of digit d for this block, then per-wave bases
+        const uint32_t d = threadIdx.x;
+        uint32_t tot;
+        const uint32_t digit_excl = block_excl_scan(totals[d], tmp, &tot);
+        uint32_t run = digit_excl + hist[(uint64_t)d * num_blocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) { const uint32_t c = cnt[w][d]; cnt[w][d] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[r] >> shift) & 0xFFu;
+            const uint32_t dst = cnt[wave][d] + rank[r];
+            keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+}
+
+size_t dvs_sort_scratch_words(uint64_t n) {
+    const uint64_t nb = (n + SORT_PART - 1) / SORT_PART;
+    return (size_t)(nb * RADIX + RADIX);
+}
+
+hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                uint32_t* vals_out, uint64_t n, int shift, uint32_t* scratch) {
+    if (n == 0) return hipSuccess;
+    const uint32_t nb = (uint32_t)((n + SORT_PART - 1) / SORT_PART);
+    uint32_t* hist = scratch;
+    uint32_t* totals = scratch + (size_t)nb * RADIX;
+    hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, hist, nb);
+    hipLaunchKernelGGL(k_sort_rowscan, dim3(RADIX), dim3(SORT_BLOCK), 0, st, hist, nb, totals);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+                       hist, totals, nb);
+    return hipGetLastError();
+}
+
+// ---- tile rect of a visible splat: identical expressions to k_preprocess_fwd -----------------------
+__device__ __forceinline__ void splat_rect(float2 m, int radius, int tiles_x, int tiles_y, int& minx, int& miny, int& maxx,
+                                           int& maxy) {
+    const float radf = (float)radius;
+    const float gx = (float)tiles_x, gy = (float)tiles_y, inv_tile = 1.0f / DVS_TILE;
+    minx = (int)fminf(gx, fmaxf(0.f, (m.x - radf) * inv_tile));
+    miny = (int)fminf(gy, fmaxf(0.f, (m.y - radf) * inv_tile));
+    maxx = (int)fminf(gx, fmaxf(0.f, (m.x + radf + (float)(DVS_TILE - 1)) * inv_tile));
+    maxy = (int)fminf(gy, fmaxf(0.f, (m.y + radf + (float)(DVS_TILE - 1)) * inv_tile));
+}
+
+// ---- A3: scan of tiles_touched in depth-sorted order ------------------------------------------------
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ tiles_touched,
+                uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
+    const uint32_t v = j < n ? tiles_touched[sorted_ids[j]] : 0u;
+    uint32_t tot;
+    (void)block_excl_scan(v, tmp, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint64_t* __restrict__ total) {
+    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < num_blocks; base += SORT_BLOCK) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = idx < num_blocks ? block_sums[idx] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, tmp, &tot);
+        if (idx < num_blocks) block_sums[idx] = (uint32_t)(carry + ex);
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+size_t dvs_scan_scratch_words(int n) { return (size_t)((n + SORT_BLOCK - 1) / SORT_BLOCK) + 1; }
+
+hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
+                                uint32_t* block_offsets, uint64_t* total_dev) {
+    const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
+    if (nb > 0) hipLaunchKernelGGL(k_tile_blocksum, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, tiles_touched, block_offsets);
+    hipLaunchKernelGGL(k_tile_scan_blocks, dim3(1), dim3(SORT_BLOCK), 0, st, block_offsets, nb, total_dev);
+    return hipGetLastError();
+}
+
+// ---- A4: duplicate with keys, in depth-sorted order ---------------------------------------------------
+#define DUP_COOP_THRESHOLD 16
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ tiles_touched,
+            const uint32_t* __restrict__ block_offsets, const int* __restrict__ radii, const float2* __restrict__ mean2d,
+            int tiles_x, int tiles_y, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat) {
+    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
+    uint32_t id = 0, touched = 0;
+    if (j < n) { id = sorted_ids[j]; touched = tiles_touched[id]; }
+    uint32_t tot;
+    uint32_t off = block_excl_scan(touched, tmp, &tot) + block_offsets[blockIdx.x];
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (touched > 0) splat_rect(mean2d[id], radii[id], tiles_x, tiles_y, minx, miny, maxx, maxy);
+    const int w = maxx - minx;
+    // small rects: the owning lane emits its tiles (row-major inside the rect)
+    if (touched > 0 && touched <= DUP_COOP_THRESHOLD) {
+        for (int y = miny; y < maxy; ++y)
+            for (int x = minx; x < maxx; ++x) {
+                inst_tile[off] = (uint32_t)(y * tiles_x + x);
+                inst_splat[off] = id;
+                ++off;
+            }
+    }
+    // large rects: the whole wave emits one splat's tiles, 64 per step
+    uint64_t big = __ballot(touched > DUP_COOP_THRESHOLD);
+    const uint32_t lane = lane_id();
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t b_id = __shfl(id, src, 64), b_touched = __shfl(touched, src, 64), b_off = __shfl(off, src, 64);
+        const int b_minx = __shfl(minx, src, 64), b_miny = __shfl(miny, src, 64), b_w = __shfl(w, src, 64);
+        for (uint32_t k = lane; k < b_touched; k += 64) {
+            const int y = b_miny + (int)(k / (uint32_t)b_w), x = b_minx + (int)(k % (uint32_t)b_w);
+            inst_tile[b_off + k] = (uint32_t)(y * tiles_x + x);
+            inst_splat[b_off + k] = b_id;
+        }
+    }
+}
+
+hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
+                                const uint32_t* block_offsets, const int* radii, const float* mean2d, int tiles_x,
+                                int tiles_y, uint32_t* inst_tile, uint32_t* inst_splat) {
+    const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, tiles_touched, block_offsets, radii,
+                       (const float2*)mean2d, tiles_x, tiles_y, inst_tile, inst_splat);
+    return hipGetLastError();
+}
+
+// ---- A6: tile ranges -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_tile_ranges(uint64_t T, const uint32_t* __restrict__ sorted_tile, uint2* __restrict__ ranges) {
+    const uint64_t j = (uint64_t)blockIdx.x * SORT_BLOCK + threadIdx.x;
+    if (j >= T) return;
+    const uint32_t t = sorted_tile[j];
+    if (j == 0 || sorted_tile[j - 1] != t) ranges[t].x = (uint32_t)j;
+    if (j + 1 == T || sorted_tile[j + 1] != t) ranges[t].y = (uint32_t)(j + 1);
+}
+
+hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles) {
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (T == 0) return hipSuccess;
+    const uint32_t nb = (uint32_t)((T + SORT_BLOCK - 1) / SORT_BLOCK);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(nb), dim3(SORT_BLOCK), 0, st, T, sorted_tile, (uint2*)ranges);
+    return hipGetLastError();
+}
+
+// ---- parity export: canonical 64-bit keys -------------------------------------------------------------------
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_export_keys(uint64_t T, const uint32_t* __restrict__ sorted_tile, const uint32_t* __restrict__ sorted_splat,
+              const float* __restrict__ depth, uint64_t* __restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * SORT_BLOCK + threadIdx.x;
+    if (j >= T) return;
+    out[j] = ((uint64_t)sorted_tile[j] << 32) | (uint64_t)__float_as_uint(depth[sorted_splat[j]]);
+}
+
+hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, const uint32_t* sorted_splat,
+                                  const float* depth, uint64_t* out_keys) {
+    if (T == 0) return hipSuccess;
+    const uint32_t nb = (uint32_t)((T + SORT_BLOCK - 1) / SORT_BLOCK);
+    hipLaunchKernelGGL(k_export_keys, dim3(nb), dim3(SORT_BLOCK), 0, st, T, sorted_tile, sorted_splat, depth, out_keys);
+    return hipGetLastError();
+}

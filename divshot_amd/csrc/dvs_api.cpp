@@ -1,0 +1,374 @@
+// dvs_api.cpp — the C-ABI of libdvsraster.so (include/dvs_raster.h): context, HBM arenas, and the
+// host-side orchestration of one forward / backward pass of the rasterizer on one MI355X.
+//
+// Replaces, behind a plain-C surface, what the reference's closed `gsplatrast` CUDA library does for
+// `gstrain`'s train_step() (call sites application/diverseshot-cli/source/gs_train.cpp:156,
+// application/editor/source/editor.cpp:1620).
+//
+// HBM layout (all arenas are ctx-owned, grow-only, sized for max_splats / max image at create):
+//   per splat   : radii i32 | mean2d f32x2 | depth f32 | conic_opacity f32x4 | rgb f32x3 | flags u32 |
+//                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 64 B/splat
+//   per instance: tile u32 x2 | splat u32 x2 (ping-pong)                                              = 16 B/instance
+//   per tile    : range u32x2          per pixel: final_T f32, n_contrib u32
+//   backward    : dL_dmean2d f32x2 | dL_dconic_opacity f32x4 | dL_drgb f32x3 | absgrad f32x2        = 44 B/splat
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/dvs_raster.h"
+#include "dvs_kernels.h"
+
+static thread_local std::string g_last_error;
+static void set_error(const char* what, hipError_t e, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+}
+#define HIPCHECK(expr)                                                   \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) { set_error(#expr, _e, __FILE__, __LINE__); return DVS_ERR_HIP; } \
+    } while (0)
+
+namespace {
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return DVS_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4;                 // 25 % headroom so a growing scene does not realloc every step
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, need); want = need; }
+        if (e != hipSuccess) { set_error("hipMalloc", e, __FILE__, __LINE__); p = nullptr; return DVS_ERR_HIP; }
+        bytes = want;
+        return DVS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+DvsCam to_dev_cam(const dvs_camera& c) {
+    DvsCam d;
+    memcpy(d.view, c.view, sizeof d.view); memcpy(d.proj, c.proj, sizeof d.proj);
+    d.tan_fovx = c.tan_fovx; d.tan_fovy = c.tan_fovy; d.focal_x = c.focal_x; d.focal_y = c.focal_y;
+    memcpy(d.campos, c.campos, sizeof d.campos);
+    d.width = c.width; d.height = c.height; memcpy(d.bg, c.bg, sizeof d.bg);
+    return d;
+}
+int bits_for(uint32_t max_value) { int b = 0; while (max_value) { ++b; max_value >>= 1; } return b; }
+}  // namespace
+
+struct dvs_ctx {
+    int device = 0;
+    size_t max_splats = 0;
+    int max_w = 0, max_h = 0;
+    Buf radii, mean2d, depth, conic_opacity, rgb, flags, tiles_touched, key[2], ids[2], scan_blocks;
+    Buf inst_tile[2], inst_splat[2];
+    Buf sort_scratch, tmp_keys, tmp_vals;
+    Buf ranges, final_T, n_contrib;
+    Buf g_mean2d, g_conic_opacity, g_rgb, g_absgrad;
+    uint64_t* total_dev = nullptr;
+    uint64_t* total_host = nullptr;      // pinned
+    dvs_fwd_state st{};
+    bool have_fwd = false;
+    // stage timing
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    std::vector<const char*> ev_names;
+    size_t ev_used = 0;
+    std::vector<const char*> out_names;
+    std::vector<float> out_ms;
+    std::vector<std::pair<const char*, std::pair<size_t, size_t>>> spans;   // name -> (event idx begin, end)
+};
+
+namespace {
+struct StageTimer {
+    dvs_ctx* c; hipStream_t st;
+    StageTimer(dvs_ctx* c_, hipStream_t s) : c(c_), st(s) {}
+    size_t mark() {
+        if (!c->timing) return 0;
+        if (c->ev_used == c->events.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->events.push_back(e); }
+        (void)hipEventRecord(c->events[c->ev_used], st);
+        return c->ev_used++;
+    }
+    void span(const char* name, size_t a, size_t b) { if (c->timing) c->spans.push_back({name, {a, b}}); }
+};
+void timing_reset(dvs_ctx* c) { c->ev_used = 0; c->spans.clear(); }
+void timing_collect(dvs_ctx* c, bool append) {
+    if (!c->timing) return;
+    if (!append) { c->out_names.clear(); c->out_ms.clear(); }
+    for (auto& s : c->spans) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(c->events[s.second.second]);
+        (void)hipEventElapsedTime(&ms, c->events[s.second.first], c->events[s.second.second]);
+        c->out_names.push_back(s.first); c->out_ms.push_back(ms);
+    }
+}
+
+int ensure_splat_arenas(dvs_ctx* c, size_t n) {
+    int r;
+#define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
+    ENS(radii, n * 4) ENS(mean2d, n * 8) ENS(depth, n * 4) ENS(conic_opacity, n * 16) ENS(rgb, n * 12)
+    ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
+    ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
+    ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)
+    ENS(g_mean2d, n * 8) ENS(g_conic_opacity, n * 16) ENS(g_rgb, n * 12) ENS(g_absgrad, n * 8)
+#undef ENS
+    return DVS_OK;
+}
+int ensure_image_arenas(dvs_ctx* c, int w, int h) {
+    const size_t P = (size_t)w * h;
+    const size_t tiles = (size_t)((w + DVS_TILE - 1) / DVS_TILE) * ((h + DVS_TILE - 1) / DVS_TILE);
+    int r;
+    if ((r = c->ranges.ensure(tiles * 8)) != DVS_OK) return r;
+    if ((r = c->final_T.ensure(P * 4)) != DVS_OK) return r;
+    if ((r = c->n_contrib.ensure(P * 4)) != DVS_OK) return r;
+    return DVS_OK;
+}
+int ensure_instance_arenas(dvs_ctx* c, uint64_t T) {
+    int r;
+    for (int k = 0; k < 2; ++k) {
+        if ((r = c->inst_tile[k].ensure(T * 4)) != DVS_OK) return r;
+        if ((r = c->inst_splat[k].ensure(T * 4)) != DVS_OK) return r;
+    }
+    if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(T) * 4)) != DVS_OK) return r;
+    return DVS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* dvs_last_error(void) { return g_last_error.c_str(); }
+const char* dvs_version(void) { return "divshot_amd raster 0.1 (gfx950)"; }
+
+dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device < 0 || device >= count) {
+        g_last_error = "dvs_create: no such HIP device (the rasterizer has no CPU fallback)";
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e, __FILE__, __LINE__); return nullptr; }
+    dvs_ctx* c = new dvs_ctx();
+    c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h;
+    if (hipMalloc((void**)&c->total_dev, 8) != hipSuccess || hipHostMalloc((void**)&c->total_host, 8, hipHostMallocDefault) != hipSuccess) {
+        g_last_error = "dvs_create: hipMalloc failed";
+        delete c;
+        return nullptr;
+    }
+    if (ensure_splat_arenas(c, max_splats) != DVS_OK || ensure_image_arenas(c, max_w, max_h) != DVS_OK ||
+        ensure_instance_arenas(c, (uint64_t)max_splats * 4) != DVS_OK) {
+        dvs_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void dvs_destroy(dvs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    Buf* all[] = {&c->radii, &c->mean2d, &c->depth, &c->conic_opacity, &c->rgb, &c->flags, &c->tiles_touched, &c->key[0], &c->key[1],
+                  &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
+                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_mean2d,
+                  &c->g_conic_opacity, &c->g_rgb, &c->g_absgrad};
+    for (Buf* b : all) b->release();
+    if (c->total_dev) (void)hipFree(c->total_dev);
+    if (c->total_host) (void)hipHostFree(c->total_host);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                       float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered) {
+    if (!c || !p || !cam || !opts || !out_rgb) { g_last_error = "dvs_raster_forward: null argument"; return DVS_ERR_INVALID; }
+    if (p->n < 0 || cam->width <= 0 || cam->height <= 0 || opts->sh_degree < 0 || opts->sh_degree > 3) {
+        g_last_error = "dvs_raster_forward: bad n / image size / sh_degree"; return DVS_ERR_INVALID;
+    }
+    if ((size_t)p->n > c->max_splats || cam->width > c->max_w || cam->height > c->max_h) {
+        g_last_error = "dvs_raster_forward: exceeds the capacity given to dvs_create"; return DVS_ERR_CAPACITY;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int n = p->n, W = cam->width, H = cam->height;
+    const int tiles_x = (W + DVS_TILE - 1) / DVS_TILE, tiles_y = (H + DVS_TILE - 1) / DVS_TILE, tiles = tiles_x * tiles_y;
+    const DvsCam dcam = to_dev_cam(*cam);
+    c->have_fwd = false;
+    timing_reset(c);
+    StageTimer tm(c, st);
+
+    // A2 preprocess
+    size_t e0 = tm.mark();
+    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree,
+                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->mean2d.as<float>(),
+                                       c->depth.as<float>(), c->conic_opacity.as<float>(), c->rgb.as<float>(),
+                                       c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
+                                       c->ids[0].as<uint32_t>()));
+    size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
+    // A5 (low 32 key bits): depth sort over splats, 4 x 8-bit LSD passes
+    int cur = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        HIPCHECK(dvs_launch_sort_pass(st, c->key[cur].as<uint32_t>(), c->ids[cur].as<uint32_t>(), c->key[cur ^ 1].as<uint32_t>(),
+                                      c->ids[cur ^ 1].as<uint32_t>(), (uint64_t)n, pass * 8, c->sort_scratch.as<uint32_t>()));
+        cur ^= 1;
+    }
+    size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
+    // A3 scan in depth order
+    HIPCHECK(dvs_launch_tile_scan(st, n, c->ids[cur].as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
+                                  c->total_dev));
+    HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 8, hipMemcpyDeviceToHost, st));
+    size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
+    HIPCHECK(hipStreamSynchronize(st));
+    const uint64_t T = *c->total_host;
+    if (T >= (1ull << 32)) { g_last_error = "dvs_raster_forward: more than 2^32 tile instances"; return DVS_ERR_CAPACITY; }
+    { int r = ensure_instance_arenas(c, T ? T : 1); if (r != DVS_OK) return r; }
+
+    // A4 duplicate
+    size_t e4 = tm.mark();
+    HIPCHECK(dvs_launch_duplicate(st, n, c->ids[cur].as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
+                                  c->radii.as<int>(), c->mean2d.as<float>(), tiles_x, tiles_y, c->inst_tile[0].as<uint32_t>(),
+                                  c->inst_splat[0].as<uint32_t>()));
+    size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
+    // A5 (high key bits): tile-id sort over instances
+    int icur = 0;
+    const int tile_bits = bits_for((uint32_t)(tiles - 1));
+    for (int shift = 0; shift < tile_bits; shift += 8) {
+        HIPCHECK(dvs_launch_sort_pass(st, c->inst_tile[icur].as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+                                      c->inst_tile[icur ^ 1].as<uint32_t>(), c->inst_splat[icur ^ 1].as<uint32_t>(), T, shift,
+                                      c->sort_scratch.as<uint32_t>()));
+        icur ^= 1;
+    }
+    size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
+    // A6 ranges
+    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles));
+    size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
+    // A7 composite
+    HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+                                   c->mean2d.as<float>(), c->conic_opacity.as<float>(), c->rgb.as<float>(), cam->bg, out_rgb,
+                                   c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
+    size_t e8 = tm.mark(); tm.span("render_fwd", e7, e8);
+
+    dvs_fwd_state& s = c->st;
+    s.radii = c->radii.as<int32_t>(); s.mean2d = c->mean2d.as<float>(); s.depth = c->depth.as<float>();
+    s.conic_opacity = c->conic_opacity.as<float>(); s.rgb = c->rgb.as<float>(); s.flags = c->flags.as<uint32_t>();
+    s.tiles_touched = c->tiles_touched.as<uint32_t>();
+    s.sorted_tile = c->inst_tile[icur].as<uint32_t>(); s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
+    s.ranges = c->ranges.as<uint32_t>(); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
+    s.num_rendered = T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y; s._pad = 0;
+    c->have_fwd = true;
+    if (saved) *saved = s;
+    if (num_rendered) *num_rendered = T;
+    if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, false); }
+    return DVS_OK;
+}
+
+int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                        const float* dL_drgb, const dvs_splat_grads* out) {
+    if (!c || !p || !cam || !opts || !dL_drgb || !out) { g_last_error = "dvs_raster_backward: null argument"; return DVS_ERR_INVALID; }
+    if (!c->have_fwd || c->st.n != p->n || c->st.width != cam->width || c->st.height != cam->height) {
+        g_last_error = "dvs_raster_backward: no matching forward on this context"; return DVS_ERR_STATE;
+    }
+    if (!out->pos || !out->sh0 || !out->shN || !out->opacity || !out->scale || !out->rot) {
+        g_last_error = "dvs_raster_backward: null gradient row pointer"; return DVS_ERR_INVALID;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int n = p->n;
+    const dvs_fwd_state& s = c->st;
+    const DvsCam dcam = to_dev_cam(*cam);
+    timing_reset(c);
+    StageTimer tm(c, st);
+    size_t e0 = tm.mark();
+    HIPCHECK(hipMemsetAsync(c->g_mean2d.p, 0, (size_t)n * 8, st));
+    HIPCHECK(hipMemsetAsync(c->g_conic_opacity.p, 0, (size_t)n * 16, st));
+    HIPCHECK(hipMemsetAsync(c->g_rgb.p, 0, (size_t)n * 12, st));
+    float* absg = nullptr;
+    if (opts->absgrad) { HIPCHECK(hipMemsetAsync(c->g_absgrad.p, 0, (size_t)n * 8, st)); absg = c->g_absgrad.as<float>(); }
+    size_t e1 = tm.mark(); tm.span("bwd_zero", e0, e1);
+    HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.mean2d, s.conic_opacity,
+                                   s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_mean2d.as<float>(),
+                                   c->g_conic_opacity.as<float>(), c->g_rgb.as<float>(), absg));
+    size_t e2 = tm.mark(); tm.span("render_bwd", e1, e2);
+    HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
+                                       s.radii, s.flags, c->g_mean2d.as<float>(), c->g_conic_opacity.as<float>(), c->g_rgb.as<float>(),
+                                       out->pos, out->sh0, out->shN, out->opacity, out->scale, out->rot, opts->accumulate));
+    if (out->absgrad2d && absg) {
+        if (opts->accumulate) { g_last_error = "dvs_raster_backward: absgrad2d with accumulate is not supported"; return DVS_ERR_INVALID; }
+        HIPCHECK(hipMemcpyAsync(out->absgrad2d, absg, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (out->mean2d) HIPCHECK(hipMemcpyAsync(out->mean2d, c->g_mean2d.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    size_t e3 = tm.mark(); tm.span("preprocess_bwd", e2, e3);
+    if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, true); }
+    return DVS_OK;
+}
+
+int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals, uint64_t n, int bit_lo, int bit_hi) {
+    if (!c || !keys || !vals || bit_lo < 0 || bit_hi > 32 || bit_lo > bit_hi) { g_last_error = "dvs_sort_pairs_u32: bad argument"; return DVS_ERR_INVALID; }
+    HIPCHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return DVS_OK;
+    int r;
+    if ((r = c->tmp_keys.ensure(n * 4)) != DVS_OK) return r;
+    if ((r = c->tmp_vals.ensure(n * 4)) != DVS_OK) return r;
+    if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(n) * 4)) != DVS_OK) return r;
+    uint32_t* k[2] = {keys, c->tmp_keys.as<uint32_t>()};
+    uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
+    int cur = 0;
+    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        HIPCHECK(dvs_launch_sort_pass(st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, shift, c->sort_scratch.as<uint32_t>()));
+        cur ^= 1;
+    }
+    if (cur == 1) {
+        HIPCHECK(hipMemcpyAsync(keys, k[1], n * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(hipMemcpyAsync(vals, v[1], n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return DVS_OK;
+}
+
+int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
+    if (!c || !out_keys) { g_last_error = "dvs_export_sorted_keys: null argument"; return DVS_ERR_INVALID; }
+    if (!c->have_fwd) { g_last_error = "dvs_export_sorted_keys: no forward state"; return DVS_ERR_STATE; }
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(dvs_launch_export_keys((hipStream_t)stream, c->st.num_rendered, c->st.sorted_tile, c->st.sorted_splat, c->st.depth, out_keys));
+    return DVS_OK;
+}
+
+int dvs_get_bwd_intermediates(dvs_ctx* c, const float** m, const float** co, const float** rgb) {
+    if (!c) return DVS_ERR_INVALID;
+    if (m) *m = c->g_mean2d.as<float>();
+    if (co) *co = c->g_conic_opacity.as<float>();
+    if (rgb) *rgb = c->g_rgb.as<float>();
+    return DVS_OK;
+}
+
+int dvs_enable_stage_timing(dvs_ctx* c, int enable) { if (!c) return DVS_ERR_INVALID; c->timing = enable != 0; return DVS_OK; }
+int dvs_get_stage_timing(dvs_ctx* c, const char*** names, const float** ms) {
+    if (!c) return 0;
+    if (names) *names = c->out_names.data();
+    if (ms) *ms = c->out_ms.data();
+    return (int)c->out_names.size();
+}
+
+int dvs_memcpy_d2h(dvs_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!c) return DVS_ERR_INVALID;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return DVS_OK;
+}
+int dvs_memcpy_h2d(dvs_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!c) return DVS_ERR_INVALID;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return DVS_OK;
+}
+void* dvs_device_malloc(dvs_ctx* c, size_t bytes) {
+    if (!c) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+void dvs_device_free(dvs_ctx* c, void* p) { if (c && p) { (void)hipSetDevice(c->device); (void)hipFree(p); } }
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// dvs_kernels.h — host-callable launchers of the gfx950 kernels (internal to libdvsraster.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dvs_device.h"
+
+// preprocess.hip
+hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, const float* sh0, const float* shN,
+                                     const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
+                                     int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* mean2d,
+                                     float* depth, float* conic_opacity, float* rgb, uint32_t* flags,
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids);
+hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
+                                     const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
+                                     const int* radii, const uint32_t* flags, const float* dL_dmean2d,
+                                     const float* dL_dconic_opacity, const float* dL_drgb, float* g_pos, float* g_sh0,
+                                     float* g_shN, float* g_opacity, float* g_scale, float* g_rot, int accumulate);
+
+// binning.hip
+// Number of uint32 scratch words dvs_launch_sort_pass needs for n items.
+size_t dvs_sort_scratch_words(uint64_t n);
+// One stable LSD pass (8-bit digit at `shift`) of (key,val) pairs: in -> out. n is read on the host.
+hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                uint32_t* vals_out, uint64_t n, int shift, uint32_t* scratch);
+// A3: offsets over tiles_touched in depth-sorted order. Writes block offsets and the total (device + pinned host).
+size_t dvs_scan_scratch_words(int n);
+hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
+                                uint32_t* block_offsets, uint64_t* total_dev);
+// A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order.
+hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
+                                const uint32_t* block_offsets, const int* radii, const float* mean2d, int tiles_x,
+                                int tiles_y, uint32_t* inst_tile, uint32_t* inst_splat);
+// A6: per-tile [start,end) from the sorted tile ids.
+hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles);
+// canonical 64-bit keys of the sorted list (parity export)
+hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, const uint32_t* sorted_splat,
+                                  const float* depth, uint64_t* out_keys);
+
+// render.hip
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
+                                 const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
+                                 const float* rgb, const float bg[3], float* out_color, float* final_T,
+                                 uint32_t* n_contrib);
+hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
+                                 const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
+                                 const float* rgb, const float bg[3], const float* final_T, const uint32_t* n_contrib,
+                                 const float* dL_dout, float* dL_dmean2d, float* dL_dconic_opacity, float* dL_drgb,
+                                 float* absgrad /*nullable*/);

@@ -1,0 +1,455 @@
+// preprocess.hip — A2 (project / preprocess forward) and A9 (preprocess backward) for gfx950.
+// Built with -ffp-contract=off: every expression that feeds an integer decision (radius, tile rect,
+// sort key) is evaluated in a fixed IEEE order so bins are bit-exact against the CPU oracle.
+//
+// Reference anchors (fenghuayumo/DIVSHOT; the trainer itself is closed source):
+//   EWA projection gsplat_vs.hlsl:74-110 · cov3D gsplat_vs.hlsl:171-209 · low-pass/eigen gsplat_vs.hlsl:304-311 ·
+//   AA factor gsplat_vs.hlsl:296-301 · ndc2Pix gsplat_vs.hlsl:211-214 · opacity cut gsplat_vs.hlsl:269 ·
+//   SH gsplat_sh.hlsl:42-124 · activations gaussian_model.cpp:137-159.
+//
+// Both kernels are HBM-streaming (236 B of parameters per splat, ~400 flop): one lane per splat.
+// The 45-float shN row (76 % of the bytes) is moved through LDS so that global traffic is
+// 16-B-per-lane coalesced while each lane still consumes / produces its own row.
+#include "dvs_device.h"
+#include "dvs_kernels.h"
+
+#define PP_BLOCK 256
+
+// ---- cooperative row staging: rows of RW floats per splat, block of PP_BLOCK splats ---------------
+// global [n, RW] -> lds[PP_BLOCK * RW]; the row of lane t starts at lds + t*RW (RW odd => conflict-free).
+template <int RW>
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ g, float* lds, int64_t base_splat, int n) {
+    const int64_t first = base_splat * RW;
+    const int64_t total = (int64_t)n * RW;
+    int64_t cnt = (int64_t)PP_BLOCK * RW;
+    if (first + cnt > total) cnt = total - first;
+    // 16-byte vector path when the block's first float is 16-B aligned (base_splat multiple of 4 and RW*4 bytes...)
+    const float* src = g + first;
+    if (((uintptr_t)src & 15) == 0) {
+        const int nvec = (int)(cnt >> 2);
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(lds);
+        for (int v = threadIdx.x; v < nvec; v += PP_BLOCK) d4[v] = s4[v];
+        for (int e = (nvec << 2) + threadIdx.x; e < cnt; e += PP_BLOCK) lds[e] = src[e];
+    } else {
+        for (int e = threadIdx.x; e < cnt; e += PP_BLOCK) lds[e] = src[e];
+    }
+}
+template <int RW, bool ACCUM>
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ g, const float* lds, int64_t base_splat, int n) {
+    const int64_t first = base_splat * RW;
+    const int64_t total = (int64_t)n * RW;
+    int64_t cnt = (int64_t)PP_BLOCK * RW;
+    if (first + cnt > total) cnt = total - first;
+    float* dst = g + first;
+    if (((uintptr_t)dst & 15) == 0) {
+        const int nvec = (int)(cnt >> 2);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const float4* s4 = reinterpret_cast<const float4*>(lds);
+        for (int v = threadIdx.x; v < nvec; v += PP_BLOCK) {
+            float4 x = s4[v];
+            if (ACCUM) { const float4 o = d4[v]; x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w; }
+            d4[v] = x;
+        }
+        for (int e = (nvec << 2) + threadIdx.x; e < cnt; e += PP_BLOCK) dst[e] = ACCUM ? dst[e] + lds[e] : lds[e];
+    } else {
+        for (int e = threadIdx.x; e < cnt; e += PP_BLOCK) dst[e] = ACCUM ? dst[e] + lds[e] : lds[e];
+    }
+}
+
+// ---- A2 ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PP_BLOCK)
+k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__ sh0, const float* __restrict__ shN,
+                 const float* __restrict__ opacity, const float* __restrict__ scale, const float* __restrict__ rot,
+                 DvsCam cam, int deg, int antialias, int tiles_x, int tiles_y,
+                 int* __restrict__ radii, float2* __restrict__ mean2d, float* __restrict__ depth,
+                 float4* __restrict__ conic_opacity, float* __restrict__ rgb, uint32_t* __restrict__ flags,
+                 uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] when deg>0
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int i = (int)(base + threadIdx.x);
+    if (deg > 0) {
+        stage_rows_in<45>(shN, lds, base, n);
+        __syncthreads();
+    }
+    if (i >= n) return;
+
+    int out_radius = 0;
+    uint32_t out_tiles = 0, out_flags = 0, out_key = 0xFFFFFFFFu;
+    float2 out_mean = make_float2(0.f, 0.f);
+    float out_depth = 0.f;
+    float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
+    float out_rgb[3] = {0.f, 0.f, 0.f};
+
+    do {
+        const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
+        const float tx = dvs_xform(cam.view, px, py, pz, 0);
+        const float ty = dvs_xform(cam.view, px, py, pz, 1);
+        const float tz = dvs_xform(cam.view, px, py, pz, 2);
+        if (!(tz > DVS_NEAR)) break;
+        const float hx = dvs_xform(cam.proj, px, py, pz, 0);
+        const float hy = dvs_xform(cam.proj, px, py, pz, 1);
+        const float hw = dvs_xform(cam.proj, px, py, pz, 3);
+        const float pw = 1.0f / (hw + 0.0000001f);
+        const float ndc_x = hx * pw, ndc_y = hy * pw;
+
+        float s[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = dvs_exp_det(scale[3 * (int64_t)i + k]);
+        const float4 q4 = reinterpret_cast<const float4*>(rot)[i];
+        const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
+        const float qn = __fsqrt_rn(((qr * qr + qx * qx) + qy * qy) + qz * qz);
+        if (!(qn > 0.f)) break;
+        const float inv_qn = 1.0f / qn;
+        float R[9];
+        dvs_quat_to_rot(qr * inv_qn, qx * inv_qn, qy * inv_qn, qz * inv_qn, R);
+        float c3[6];
+        dvs_cov3d(s, R, c3);
+
+        const float limx = DVS_FOV_GUARD * cam.tan_fovx, limy = DVS_FOV_GUARD * cam.tan_fovy;
+        const float txtz = tx / tz, tytz = ty / tz;
+        uint32_t fl = 0;
+        if (txtz < -limx || txtz > limx) fl |= DVS_FLAG_CLAMP_X;
+        if (tytz < -limy || tytz > limy) fl |= DVS_FLAG_CLAMP_Y;
+        const float txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        const float tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float fx = cam.focal_x, fy = cam.focal_y;
+        const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz);
+        const float J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
+        float T0[3], T1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T0[k] = J00 * cam.view[k * 4 + 0] + J02 * cam.view[k * 4 + 2];
+            T1[k] = J11 * cam.view[k * 4 + 1] + J12 * cam.view[k * 4 + 2];
+        }
+        const float v0x = (c3[0] * T0[0] + c3[1] * T0[1]) + c3[2] * T0[2];
+        const float v0y = (c3[1] * T0[0] + c3[3] * T0[1]) + c3[4] * T0[2];
+        const float v0z = (c3[2] * T0[0] + c3[4] * T0[1]) + c3[5] * T0[2];
+        const float v1x = (c3[0] * T1[0] + c3[1] * T1[1]) + c3[2] * T1[2];
+        const float v1y = (c3[1] * T1[0] + c3[3] * T1[1]) + c3[4] * T1[2];
+        const float v1z = (c3[2] * T1[0] + c3[4] * T1[1]) + c3[5] * T1[2];
+        const float cxx = (T0[0] * v0x + T0[1] * v0y) + T0[2] * v0z;
+        const float cxy = (T0[0] * v1x + T0[1] * v1y) + T0[2] * v1z;
+        const float cyy = (T1[0] * v1x + T1[1] * v1y) + T1[2] * v1z;
+
+        const float a = cxx + DVS_LOWPASS, b = cxy, c = cyy + DVS_LOWPASS;
+        const float det = a * c - b * b;
+        if (!(det > 0.f)) break;
+        float opac = dvs_sigmoid_det(opacity[i]);
+        if (antialias) {
+            const float det_orig = cxx * cyy - b * b;
+            const float aa = __fsqrt_rn(fmaxf(0.f, det_orig / det));
+            opac = opac * aa;
+        }
+        if (!(opac > DVS_ALPHA_MIN)) break;
+        const float det_inv = 1.0f / det;
+        const float mid = 0.5f * (a + c);
+        const float lam = mid + __fsqrt_rn(fmaxf(0.1f, mid * mid - det));
+        const float radf = ceilf(3.0f * __fsqrt_rn(lam));
+        const float m2x = ((ndc_x + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
+        const float m2y = ((ndc_y + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
+        const float gx = (float)tiles_x, gy = (float)tiles_y, inv_tile = 1.0f / DVS_TILE;
+        const int rminx = (int)fminf(gx, fmaxf(0.f, (m2x - radf) * inv_tile));
+        const int rminy = (int)fminf(gy, fmaxf(0.f, (m2y - radf) * inv_tile));
+        const int rmaxx = (int)fminf(gx, fmaxf(0.f, (m2x + radf + (float)(DVS_TILE - 1)) * inv_tile));
+        const int rmaxy = (int)fminf(gy, fmaxf(0.f, (m2y + radf + (float)(DVS_TILE - 1)) * inv_tile));
+        const int touched = (rmaxx - rminx) * (rmaxy - rminy);
+        if (touched <= 0) break;
+
+        const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+        const float dl = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+        const float inv_dl = 1.0f / dl;
+        float bas[16];
+        dvs_sh_basis(deg, dx * inv_dl, dy * inv_dl, dz * inv_dl, bas);
+        const int ncoef = (deg + 1) * (deg + 1);
+        const float* row = lds + threadIdx.x * 45;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float col = bas[0] * sh0[3 * (int64_t)i + ch];
+            for (int k = 1; k < ncoef; ++k) col = col + bas[k] * row[(k - 1) * 3 + ch];
+            col = col + 0.5f;
+            if (col < 0.f) { fl |= (1u << ch); col = 0.f; }
+            out_rgb[ch] = col;
+        }
+        out_radius = (int)fminf(radf, (float)(1 << 30));
+        out_mean = make_float2(m2x, m2y);
+        out_depth = tz;
+        out_key = __float_as_uint(tz);
+        out_co = make_float4(c * det_inv, -b * det_inv, a * det_inv, opac);
+        out_flags = fl;
+        out_tiles = (uint32_t)touched;
+    } while (0);
+
+    radii[i] = out_radius;
+    mean2d[i] = out_mean;
+    depth[i] = out_depth;
+    conic_opacity[i] = out_co;
+    rgb[3 * (int64_t)i] = out_rgb[0]; rgb[3 * (int64_t)i + 1] = out_rgb[1]; rgb[3 * (int64_t)i + 2] = out_rgb[2];
+    flags[i] = out_flags;
+    tiles_touched[i] = out_tiles;
+    depth_key[i] = out_key;
+    ids[i] = (uint32_t)i;
+}
+
+// ---- A9 ---------------------------------------------------------------------------------------
+template <bool ACCUM>
+__global__ void __launch_bounds__(PP_BLOCK)
+k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
+                 const float* __restrict__ scale, const float* __restrict__ rot, DvsCam cam, int deg, int antialias,
+                 const int* __restrict__ radii, const uint32_t* __restrict__ flags,
+                 const float2* __restrict__ dL_dmean2d, const float4* __restrict__ dL_dconic_opacity,
+                 const float* __restrict__ dL_drgb,
+                 float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
+                 float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int i = (int)(base + threadIdx.x);
+    const bool valid = i < n;
+    const int radius = valid ? radii[i] : 0;
+    if (deg > 0) {
+        stage_rows_in<45>(shN, lds, base, n);
+        __syncthreads();
+    }
+    float gp[3] = {0.f, 0.f, 0.f}, gs0[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq_out[4] = {0.f, 0.f, 0.f, 0.f};
+    float g_op = 0.f;
+    float* row = lds + threadIdx.x * 45;
+
+    if (radius > 0) {
+        const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
+        const uint32_t fl = flags[i];
+        const float tx = dvs_xform(cam.view, px, py, pz, 0);
+        const float ty = dvs_xform(cam.view, px, py, pz, 1);
+        const float tz = dvs_xform(cam.view, px, py, pz, 2);
+        const float hx = dvs_xform(cam.proj, px, py, pz, 0);
+        const float hy = dvs_xform(cam.proj, px, py, pz, 1);
+        const float hw = dvs_xform(cam.proj, px, py, pz, 3);
+        const float pw = 1.0f / (hw + 0.0000001f);
+        float s[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = dvs_exp_det(scale[3 * (int64_t)i + k]);
+        const float4 q4 = reinterpret_cast<const float4*>(rot)[i];
+        const float qn = __fsqrt_rn(((q4.x * q4.x + q4.y * q4.y) + q4.z * q4.z) + q4.w * q4.w);
+        const float inv_qn = 1.0f / qn;
+        const float qr = q4.x * inv_qn, qx = q4.y * inv_qn, qy = q4.z * inv_qn, qz = q4.w * inv_qn;
+        float R[9];
+        dvs_quat_to_rot(qr, qx, qy, qz, R);
+        float c3[6];
+        dvs_cov3d(s, R, c3);
+        const float limx = DVS_FOV_GUARD * cam.tan_fovx, limy = DVS_FOV_GUARD * cam.tan_fovy;
+        const float txtz = tx / tz, tytz = ty / tz;
+        const float cl_x = fminf(limx, fmaxf(-limx, txtz)), cl_y = fminf(limy, fmaxf(-limy, tytz));
+        const float txc = cl_x * tz, tyc = cl_y * tz;
+        const float fx = cam.focal_x, fy = cam.focal_y;
+        const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz);
+        const float J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
+        float T0[3], T1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T0[k] = J00 * cam.view[k * 4 + 0] + J02 * cam.view[k * 4 + 2];
+            T1[k] = J11 * cam.view[k * 4 + 1] + J12 * cam.view[k * 4 + 2];
+        }
+        const float v0[3] = {(c3[0] * T0[0] + c3[1] * T0[1]) + c3[2] * T0[2], (c3[1] * T0[0] + c3[3] * T0[1]) + c3[4] * T0[2],
+                             (c3[2] * T0[0] + c3[4] * T0[1]) + c3[5] * T0[2]};
+        const float v1[3] = {(c3[0] * T1[0] + c3[1] * T1[1]) + c3[2] * T1[2], (c3[1] * T1[0] + c3[3] * T1[1]) + c3[4] * T1[2],
+                             (c3[2] * T1[0] + c3[4] * T1[1]) + c3[5] * T1[2]};
+        const float cxx = (T0[0] * v0[0] + T0[1] * v0[1]) + T0[2] * v0[2];
+        const float cxy = (T0[0] * v1[0] + T0[1] * v1[1]) + T0[2] * v1[2];
+        const float cyy = (T1[0] * v1[0] + T1[1] * v1[1]) + T1[2] * v1[2];
+        const float a = cxx + DVS_LOWPASS, b = cxy, c = cyy + DVS_LOWPASS;
+        const float det = a * c - b * b;
+        const float det_inv = 1.0f / det;
+
+        // 1. colour / SH
+        const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
+        const float dl = __fsqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+        const float inv_dl = 1.0f / dl;
+        const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
+        float bas[16], dbas[16][3];
+        dvs_sh_basis(deg, ux, uy, uz, bas);
+        dvs_sh_basis_grad(deg, ux, uy, uz, dbas);
+        const int ncoef = (deg + 1) * (deg + 1);
+        float gdir[3] = {0.f, 0.f, 0.f};
+        float gc[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            gc[ch] = (fl & (1u << ch)) ? 0.f : dL_drgb[3 * (int64_t)i + ch];
+            gs0[ch] = bas[0] * gc[ch];
+        }
+        for (int k = 1; k < ncoef; ++k) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float coef = row[(k - 1) * 3 + ch];
+                row[(k - 1) * 3 + ch] = bas[k] * gc[ch];       // overwrite the staged parameter with its gradient
+                gdir[0] += dbas[k][0] * coef * gc[ch]; gdir[1] += dbas[k][1] * coef * gc[ch]; gdir[2] += dbas[k][2] * coef * gc[ch];
+            }
+        }
+        for (int e = (ncoef - 1) * 3; e < 45; ++e) row[e] = 0.f;
+        {
+            const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
+            gp[0] += (gdir[0] - ux * ug) * inv_dl; gp[1] += (gdir[1] - uy * ug) * inv_dl; gp[2] += (gdir[2] - uz * ug) * inv_dl;
+        }
+
+        // 2. opacity (+ AA)
+        float g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f;
+        const float4 gco = dL_dconic_opacity[i];
+        const float sig = dvs_sigmoid_det(opacity[i]);
+        float g_sig = gco.w;
+        if (antialias) {
+            const float det_orig = cxx * cyy - b * b;
+            const float ratio = det_orig / det;
+            const float aa = __fsqrt_rn(fmaxf(0.f, ratio));
+            g_sig = gco.w * aa;
+            if (ratio > 0.f) {
+                const float g_aa = gco.w * sig;
+                const float g_ratio = g_aa * 0.5f / aa;
+                const float g_do = g_ratio * det_inv;
+                const float g_db = -g_ratio * det_orig * det_inv * det_inv;
+                g_cxx += g_do * cyy + g_db * c;
+                g_cyy += g_do * cxx + g_db * a;
+                g_cxy += -2.f * b * (g_do + g_db);
+            }
+        }
+        g_op = g_sig * sig * (1.f - sig);
+
+        // 3. conic
+        {
+            const float Ssum = (gco.x * c - gco.y * b) + gco.z * a;
+            const float g_det = -Ssum * det_inv * det_inv;
+            g_cxx += gco.z * det_inv + g_det * c;
+            g_cyy += gco.x * det_inv + g_det * a;
+            g_cxy += -gco.y * det_inv + g_det * (-2.f * b);
+        }
+        // 4. cov2D
+        float Gm[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                Gm[r * 3 + q] = (g_cxx * T0[r] * T0[q] + g_cxy * T0[r] * T1[q]) + g_cyy * T1[r] * T1[q];
+        float gT0[3], gT1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gT0[k] = 2.f * g_cxx * v0[k] + g_cxy * v1[k];
+            gT1[k] = 2.f * g_cyy * v1[k] + g_cxy * v0[k];
+        }
+        // 5. Tm = J Wv
+        float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gJ00 += gT0[k] * cam.view[k * 4 + 0]; gJ02 += gT0[k] * cam.view[k * 4 + 2];
+            gJ11 += gT1[k] * cam.view[k * 4 + 1]; gJ12 += gT1[k] * cam.view[k * 4 + 2];
+        }
+        const float tz2 = 1.0f / (tz * tz), tz3 = tz2 / tz;
+        float g_tx = 0.f, g_ty = 0.f, g_tz = 0.f;
+        g_tz += -fx * tz2 * gJ00 - fy * tz2 * gJ11;
+        g_tz += 2.f * fx * txc * tz3 * gJ02 + 2.f * fy * tyc * tz3 * gJ12;
+        const float g_txc = -fx * tz2 * gJ02, g_tyc = -fy * tz2 * gJ12;
+        if (fl & DVS_FLAG_CLAMP_X) g_tz += g_txc * cl_x; else g_tx += g_txc;
+        if (fl & DVS_FLAG_CLAMP_Y) g_tz += g_tyc * cl_y; else g_ty += g_tyc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            gp[k] += (cam.view[k * 4 + 0] * g_tx + cam.view[k * 4 + 1] * g_ty) + cam.view[k * 4 + 2] * g_tz;
+        // 6. mean2D
+        {
+            const float2 gm = dL_dmean2d[i];
+            const float g_hx = gm.x * 0.5f * (float)cam.width * pw, g_hy = gm.y * 0.5f * (float)cam.height * pw;
+            const float g_hw = -(gm.x * 0.5f * (float)cam.width * hx + gm.y * 0.5f * (float)cam.height * hy) * pw * pw;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                gp[k] += (cam.proj[k * 4 + 0] * g_hx + cam.proj[k * 4 + 1] * g_hy) + cam.proj[k * 4 + 3] * g_hw;
+        }
+        (void)ty;
+        // 7. Sigma = M M^T
+        float M[9], gM[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) M[r * 3 + k] = R[r * 3 + k] * s[k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc += (Gm[r * 3 + q] + Gm[q * 3 + r]) * M[q * 3 + k];
+                gM[r * 3 + k] = acc;
+            }
+        float gR[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float gs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { gs += gM[r * 3 + k] * R[r * 3 + k]; gR[r * 3 + k] = gM[r * 3 + k] * s[k]; }
+            gsc[k] = gs * s[k];
+        }
+        float gq[4];
+        gq[0] = 2.f * (-qz * gR[1] + qy * gR[2] + qz * gR[3] - qx * gR[5] - qy * gR[6] + qx * gR[7]);
+        gq[1] = 2.f * (qy * gR[1] + qz * gR[2] + qy * gR[3] - 2.f * qx * gR[4] - qr * gR[5] + qz * gR[6] + qr * gR[7] - 2.f * qx * gR[8]);
+        gq[2] = 2.f * (-2.f * qy * gR[0] + qx * gR[1] + qr * gR[2] + qx * gR[3] + qz * gR[5] - qr * gR[6] + qz * gR[7] - 2.f * qy * gR[8]);
+        gq[3] = 2.f * (-2.f * qz * gR[0] - qr * gR[1] + qx * gR[2] + qr * gR[3] - 2.f * qz * gR[4] + qy * gR[5] + qx * gR[6] + qy * gR[7]);
+        const float qg = ((qr * gq[0] + qx * gq[1]) + qy * gq[2]) + qz * gq[3];
+        gq_out[0] = (gq[0] - qr * qg) * inv_qn; gq_out[1] = (gq[1] - qx * qg) * inv_qn;
+        gq_out[2] = (gq[2] - qy * qg) * inv_qn; gq_out[3] = (gq[3] - qz * qg) * inv_qn;
+    } else if (valid) {
+        for (int e = 0; e < 45; ++e) row[e] = 0.f;
+    }
+
+    if (valid) {
+        const int64_t i3 = 3 * (int64_t)i;
+        if (ACCUM) {
+            g_pos[i3] += gp[0]; g_pos[i3 + 1] += gp[1]; g_pos[i3 + 2] += gp[2];
+            g_sh0[i3] += gs0[0]; g_sh0[i3 + 1] += gs0[1]; g_sh0[i3 + 2] += gs0[2];
+            g_scale[i3] += gsc[0]; g_scale[i3 + 1] += gsc[1]; g_scale[i3 + 2] += gsc[2];
+            g_opacity[i] += g_op;
+            float4 o = reinterpret_cast<float4*>(g_rot)[i];
+            o.x += gq_out[0]; o.y += gq_out[1]; o.z += gq_out[2]; o.w += gq_out[3];
+            reinterpret_cast<float4*>(g_rot)[i] = o;
+        } else {
+            g_pos[i3] = gp[0]; g_pos[i3 + 1] = gp[1]; g_pos[i3 + 2] = gp[2];
+            g_sh0[i3] = gs0[0]; g_sh0[i3 + 1] = gs0[1]; g_sh0[i3 + 2] = gs0[2];
+            g_scale[i3] = gsc[0]; g_scale[i3 + 1] = gsc[1]; g_scale[i3 + 2] = gsc[2];
+            g_opacity[i] = g_op;
+            reinterpret_cast<float4*>(g_rot)[i] = make_float4(gq_out[0], gq_out[1], gq_out[2], gq_out[3]);
+        }
+    }
+    // shN gradient rows leave through LDS as coalesced 16-B stores (zero rows when deg == 0)
+    if (deg == 0) {
+        if (valid) for (int e = 0; e < 45; ++e) row[e] = 0.f;
+    }
+    __syncthreads();
+    stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, const float* sh0, const float* shN,
+                                     const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
+                                     int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* mean2d,
+                                     float* depth, float* conic_opacity, float* rgb, uint32_t* flags,
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids) {
+    if (n <= 0) return hipSuccess;
+    const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, sh0, shN, opacity, scale, rot, cam,
+                       deg, antialias, tiles_x, tiles_y, radii, (float2*)mean2d, depth, (float4*)conic_opacity, rgb, flags,
+                       tiles_touched, depth_key, ids);
+    return hipGetLastError();
+}
+
+hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
+                                     const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
+                                     const int* radii, const uint32_t* flags, const float* dL_dmean2d,
+                                     const float* dL_dconic_opacity, const float* dL_drgb, float* g_pos, float* g_sh0,
+                                     float* g_shN, float* g_opacity, float* g_scale, float* g_rot, int accumulate) {
+    if (n <= 0) return hipSuccess;
+    const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const size_t lds = (size_t)PP_BLOCK * 45 * sizeof(float);
+    if (accumulate)
+        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
+                           deg, antialias, radii, flags, (const float2*)dL_dmean2d, (const float4*)dL_dconic_opacity, dL_drgb,
+                           g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot);
+    else
+        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
+                           deg, antialias, radii, flags, (const float2*)dL_dmean2d, (const float4*)dL_dconic_opacity, dL_drgb,
+                           g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot);
+    return hipGetLastError();
+}

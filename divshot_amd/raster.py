@@ -1,0 +1,147 @@
+"""Rasterizer — Python handle over the dvs_* C-ABI (include/dvs_raster.h).
+
+torch supplies device buffers (`tensor.data_ptr()`) and the HIP stream; all compute runs in
+libdvsraster.so. Mirrors the two-op surface of the reference's rasterizer library (forward ->
+image + saved state, backward -> per-splat gradient rows).
+"""
+import ctypes as C
+import numpy as np
+import torch
+from ._lib import lib, Splats, Camera, Opts, FwdState, SplatGrads, check, DvsError
+
+PARAM_KEYS = ("pos", "sh0", "shN", "opacity", "scale", "rot")
+PARAM_WIDTH = {"pos": 3, "sh0": 3, "shN": 45, "opacity": 1, "scale": 3, "rot": 4}
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Rasterizer:
+    def __init__(self, device=0, max_splats=1 << 20, max_w=1920, max_h=1080):
+        if not torch.cuda.is_available():
+            raise DvsError("no HIP device visible: the rasterizer has no CPU fallback")
+        self.device = device
+        self.tdev = torch.device("cuda", device)
+        self.ctx = lib.dvs_create(device, max_splats, max_w, max_h)
+        if not self.ctx:
+            raise DvsError("dvs_create failed: " + lib.dvs_last_error().decode())
+        self.state = None
+        self._cam = None
+        self._opts = None
+        self._params = None
+
+    def close(self):
+        if self.ctx:
+            lib.dvs_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _splats(self, params):
+        n = params["pos"].shape[0]
+        for k in PARAM_KEYS:
+            t = params[k]
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), k
+            assert t.numel() == n * PARAM_WIDTH[k], k
+        return Splats(*[params[k].data_ptr() for k in PARAM_KEYS], n, 0)
+
+    def enable_timing(self, on=True):
+        check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))
+
+    def stage_timing(self):
+        names = C.POINTER(C.c_char_p)()
+        ms = C.POINTER(C.c_float)()
+        k = lib.dvs_get_stage_timing(self.ctx, C.byref(names), C.byref(ms))
+        return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    # -- the two ops -------------------------------------------------------------------------
+    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None):
+        """params: dict of CUDA float32 tensors (A0 layout). Returns out_rgb [3,H,W] (CUDA)."""
+        sp = self._splats(params)
+        opts = Opts(sh_degree, int(antialias), int(absgrad), 0)
+        if out is None:
+            out = torch.empty((3, cam.height, cam.width), dtype=torch.float32, device=self.tdev)
+        st = FwdState()
+        T = C.c_uint64(0)
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_forward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(cam), C.byref(opts),
+                                         out.data_ptr(), C.byref(st), C.byref(T)), "dvs_raster_forward")
+        self.state, self._cam, self._opts, self._params = st, cam, opts, params
+        self.num_rendered = int(T.value)
+        return out
+
+    def backward(self, dL_drgb, grads=None, accumulate=False, want_mean2d=False):
+        """dL_drgb: CUDA [3,H,W]. Returns dict of gradient tensors shaped like params (+absgrad2d / mean2d)."""
+        assert self.state is not None, "forward first"
+        params, cam = self._params, self._cam
+        n = params["pos"].shape[0]
+        if grads is None:
+            grads = {k: torch.empty_like(params[k]) for k in PARAM_KEYS}
+            accumulate = False
+        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate))
+        if self._opts.absgrad and "absgrad2d" not in grads and not accumulate:
+            grads["absgrad2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
+        if want_mean2d and "mean2d" not in grads:
+            grads["mean2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
+        g = SplatGrads(*[grads[k].data_ptr() for k in PARAM_KEYS],
+                       grads["absgrad2d"].data_ptr() if "absgrad2d" in grads else None,
+                       grads["mean2d"].data_ptr() if "mean2d" in grads else None)
+        sp = self._splats(params)
+        assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous()
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_backward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(cam), C.byref(opts),
+                                          dL_drgb.data_ptr(), C.byref(g)), "dvs_raster_backward")
+        return grads
+
+    # -- stage-level access for the parity tests --------------------------------------------------
+    def _d2h(self, ptr, shape, dtype):
+        a = np.empty(shape, dtype)
+        if a.nbytes:
+            check(lib.dvs_memcpy_d2h(self.ctx, a.ctypes.data, C.c_void_p(ptr), a.nbytes), "dvs_memcpy_d2h")
+        return a
+
+    def saved(self):
+        """Host copies of every saved forward array (dict of numpy arrays)."""
+        s = self.state
+        n, T, W, H = s.n, s.num_rendered, s.width, s.height
+        tiles = s.tiles_x * s.tiles_y
+        return {
+            "radii": self._d2h(s.radii, (n,), np.int32), "mean2d": self._d2h(s.mean2d, (n, 2), np.float32),
+            "depth": self._d2h(s.depth, (n,), np.float32), "conic_opacity": self._d2h(s.conic_opacity, (n, 4), np.float32),
+            "rgb": self._d2h(s.rgb, (n, 3), np.float32), "flags": self._d2h(s.flags, (n,), np.uint32),
+            "tiles_touched": self._d2h(s.tiles_touched, (n,), np.uint32),
+            "sorted_tile": self._d2h(s.sorted_tile, (T,), np.uint32), "vals": self._d2h(s.sorted_splat, (T,), np.uint32),
+            "ranges": self._d2h(s.ranges, (tiles, 2), np.uint32), "final_T": self._d2h(s.final_T, (H, W), np.float32),
+            "n_contrib": self._d2h(s.n_contrib, (H, W), np.uint32),
+        }
+
+    def sorted_keys(self):
+        T = self.state.num_rendered
+        buf = torch.empty((max(T, 1),), dtype=torch.int64, device=self.tdev)
+        check(lib.dvs_export_sorted_keys(self.ctx, _stream_ptr(), buf.data_ptr()), "dvs_export_sorted_keys")
+        torch.cuda.synchronize(self.tdev)
+        return buf[:T].cpu().numpy().view(np.uint64)
+
+    def bwd_intermediates(self):
+        m, co, rgb = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.dvs_get_bwd_intermediates(self.ctx, C.byref(m), C.byref(co), C.byref(rgb)))
+        n = self.state.n
+        return {"dL_dmean2d": self._d2h(m.value, (n, 2), np.float32),
+                "dL_dconic_opacity": self._d2h(co.value, (n, 4), np.float32),
+                "dL_drgb": self._d2h(rgb.value, (n, 3), np.float32)}
+
+    def sort_pairs(self, keys, vals, bit_lo=0, bit_hi=32):
+        """In-place stable LSD radix sort of CUDA uint32-as-int32 tensors."""
+        assert keys.is_cuda and vals.is_cuda and keys.numel() == vals.numel()
+        check(lib.dvs_sort_pairs_u32(self.ctx, _stream_ptr(), keys.data_ptr(), vals.data_ptr(), keys.numel(), bit_lo, bit_hi),
+              "dvs_sort_pairs_u32")
+
+
+def params_to_device(params_np, device):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in params_np.items()}

@@ -1,0 +1,171 @@
+/*
+ * dvs_raster.h — the thin C-ABI between DIVSHOT-side host C++ and the MI355X (gfx950) HIP
+ * rasterizer. Plain C: POD structs, raw device pointers, int status codes. No torch / STL types.
+ *
+ * What this boundary replaces in the reference (fenghuayumo/DIVSHOT):
+ *   The reference's trainer plugin `gstrain` (closed source; see README.md:32,46 and
+ *   diverse_utils/CMakeLists.txt:1-3, which add_subdirectory()s the absent `gsplatrast`,
+ *   `gstrain_utils`, `gstrain`) calls its CUDA rasterizer `gsplatrast` from inside
+ *   train_step() (call site application/diverseshot-cli/source/gs_train.cpp:156 and
+ *   application/editor/source/editor.cpp:1620).  The include dir for that rasterizer is
+ *   declared at CMakeLists.txt:103 / premake-dependencies.lua:38-42 but the directory is not
+ *   in the tree, so the FFI below is specified from SURVEY.md §8(b) "B2": the two-op surface
+ *   (forward returns image + saved state, backward returns the five per-splat gradient groups)
+ *   of the rasterizer lineage credited at README.md:95.
+ *
+ *   Data layout (splat parameter block, "A0") follows the reference's trainer→viewer hand-off:
+ *   getGaussian{Position,SH0,SHN,Opcaities,Scalings,Rotations}Cpu() (editor.cpp:1459-1473)
+ *   → GaussianModel::update_from_cpu memcpy sizes (diverse/source/assets/gaussian_model.cpp:60-65):
+ *   pos[N,3] sh0[N,3] shN[N,15,3] opacity[N] scale[N,3] rot[N,4] — 59 fp32 = 236 B per splat
+ *   (editor.cpp:1578), raw (pre-activation) values; activations as gaussian_model.cpp:137-159.
+ *
+ * Threading: a dvs_ctx is single-caller (one in-flight view); use one ctx per concurrent view.
+ * All work is enqueued on the hipStream_t passed in (as void*). Functions that return counts to
+ * the host synchronise that stream once (documented per function).
+ */
+#ifndef DVS_RASTER_H
+#define DVS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVS_TILE 16            /* tile edge in pixels (gaussian_common.hlsl:162-163 uses 16x16 groups) */
+#define DVS_SH_REST 15         /* higher-order SH coefficients per channel (degree 3) */
+
+/* status codes */
+enum {
+    DVS_OK = 0,
+    DVS_ERR_INVALID = 1,       /* bad argument */
+    DVS_ERR_HIP = 2,           /* a HIP runtime call failed; see dvs_last_error() */
+    DVS_ERR_CAPACITY = 3,      /* n > max_splats or image > max_w x max_h given to dvs_create */
+    DVS_ERR_STATE = 4          /* backward called without a matching forward */
+};
+
+/* A0 — splat parameter block. DEVICE pointers, SoA, raw (pre-activation) fp32.
+ *   pos[n*3]; sh0[n*3] (dc, rgb); shN[n*45] coefficient-major / channel-minor [j*3+c]
+ *   (gaussian_model.cpp:163-167); opacity[n] logit; scale[n*3] log; rot[n*4] (w,x,y,z) unnormalised
+ *   (quaternion order gsplat_vs.hlsl:189-199). */
+typedef struct dvs_splats {
+    const float* pos;
+    const float* sh0;
+    const float* shN;
+    const float* opacity;
+    const float* scale;
+    const float* rot;
+    int32_t n;
+    int32_t _pad;
+} dvs_splats;
+
+/* A1 — camera block (HOST struct; copied into kernel arguments).
+ *   view / proj are 4x4, stored so that element [c*4+r] multiplies input component c into
+ *   output component r:  out.r = m[0*4+r]*x + m[1*4+r]*y + m[2*4+r]*z + m[3*4+r]
+ *   (the convention of transformPoint4x4 at gsplat_vs.hlsl:63-72).
+ *   view: world -> camera, +Z forward, Y down (COLMAP-like; editor.cpp:2028-2029 rotates trained
+ *   models 180deg about X for display).  proj: world -> clip (full view-projection).
+ *   focal_x = width / (2 tan_fovx) (gsplat_vs.hlsl:292-293). */
+typedef struct dvs_camera {
+    float view[16];
+    float proj[16];
+    float tan_fovx, tan_fovy;
+    float focal_x, focal_y;
+    float campos[3];
+    int32_t width, height;
+    float bg[3];
+} dvs_camera;
+
+typedef struct dvs_opts {
+    int32_t sh_degree;     /* active SH degree 0..3 */
+    int32_t antialias;     /* mip-splatting opacity compensation (main.cpp:63 --mipAntiliased; gsplat_vs.hlsl:296-301) */
+    int32_t absgrad;       /* also accumulate |dL/dmean2D| (main.cpp:44 --absgrad) */
+    int32_t accumulate;    /* backward: 0 = overwrite gradient rows, 1 = add into them (multi-view batches) */
+} dvs_opts;
+
+/* Saved forward state. DEVICE pointers into ctx-owned arenas; valid until the next
+ * dvs_raster_forward on the same ctx. Exposed so the parity tests can diff every stage. */
+typedef struct dvs_fwd_state {
+    /* per splat (n) */
+    const int32_t*  radii;          /* 0 = culled */
+    const float*    mean2d;         /* [n,2] pixel coords, pixel i centre = i */
+    const float*    depth;          /* [n] view-space z */
+    const float*    conic_opacity;  /* [n,4] conic a,b,c + final opacity */
+    const float*    rgb;            /* [n,3] clamped colour */
+    const uint32_t* flags;          /* [n] bit0..2 = SH clamp (colour channel <0), bit3 = fx clamped, bit4 = fy clamped */
+    const uint32_t* tiles_touched;  /* [n] */
+    /* per instance (num_rendered), sorted by (tile, depth, splat id) */
+    const uint32_t* sorted_tile;    /* [T] tile id of each sorted instance */
+    const uint32_t* sorted_splat;   /* [T] splat id ("value") of each sorted instance */
+    /* per tile */
+    const uint32_t* ranges;         /* [tiles,2] [start,end) into the sorted lists */
+    /* per pixel */
+    const float*    final_T;        /* [H,W] */
+    const uint32_t* n_contrib;      /* [H,W] index (1-based, within tile list) of last contributor */
+    uint64_t num_rendered;          /* T */
+    int32_t n, width, height, tiles_x, tiles_y, _pad;
+} dvs_fwd_state;
+
+/* Per-splat gradient rows. DEVICE pointers, caller-owned, same shapes as dvs_splats
+ * (59 floats per splat; rows of culled splats are written as zero unless opts.accumulate). */
+typedef struct dvs_splat_grads {
+    float* pos;
+    float* sh0;
+    float* shN;
+    float* opacity;
+    float* scale;
+    float* rot;
+    float* absgrad2d;   /* [n,2] optional (may be NULL): sum over pixels of |dL/dmean2D| per axis, pixel units */
+    float* mean2d;      /* [n,2] optional (may be NULL): dL/dmean2D, pixel units (densification statistic) */
+} dvs_splat_grads;
+
+typedef struct dvs_ctx dvs_ctx;
+
+/* Create a rasterizer context on HIP device `device`. Arenas are sized for max_splats and
+ * max_w x max_h; the instance arena grows on demand. Returns NULL on failure (dvs_last_error). */
+dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h);
+void     dvs_destroy(dvs_ctx* ctx);
+
+/* Forward: A2 preprocess -> A3 scan -> A4 duplicate -> A5 radix sort -> A6 ranges -> A7 composite.
+ *   out_rgb: DEVICE [3,H,W] planar fp32.  saved: filled with pointers into ctx arenas (may be NULL).
+ *   num_rendered: host pointer, may be NULL.
+ * Synchronises `stream` once internally (reads the instance count T to size the sort). */
+int dvs_raster_forward(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
+                       const dvs_opts* opts, float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered);
+
+/* Backward: A8 composite backward -> A9 preprocess backward, using the state of the last forward on ctx.
+ *   dL_drgb: DEVICE [3,H,W] planar fp32.  out: gradient rows (see dvs_splat_grads). Asynchronous. */
+int dvs_raster_backward(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
+                        const dvs_opts* opts, const float* dL_drgb, const dvs_splat_grads* out);
+
+/* Stage-level entry points (used by the parity tests and the profiler harness). */
+/* radix sort of (u32 key, u32 value) pairs over key bits [bit_lo, bit_hi), stable, LSD, 8-bit digits.
+ * keys/vals are DEVICE arrays of length n, sorted in place (ctx scratch is used as the ping-pong buffer). */
+int dvs_sort_pairs_u32(dvs_ctx* ctx, void* stream, uint32_t* keys, uint32_t* vals, uint64_t n, int bit_lo, int bit_hi);
+/* Reconstruct the canonical 64-bit keys ((tile<<32)|depth_bits) of the sorted instance list into
+ * DEVICE out_keys[T] (parity tests compare them bit-exactly with the oracle's stable_sort). */
+int dvs_export_sorted_keys(dvs_ctx* ctx, void* stream, uint64_t* out_keys);
+
+/* Intermediate gradients of the last backward (DEVICE, ctx-owned): dL/d{mean2D[n,2], conic[n,3]+opacity[n] packed
+ * as [n,4], rgb[n,3]} — for stage-level parity of A8. */
+int dvs_get_bwd_intermediates(dvs_ctx* ctx, const float** dL_dmean2d, const float** dL_dconic_opacity, const float** dL_drgb);
+
+/* Per-stage GPU time (ms) of the last forward/backward, measured with hipEvents on the caller's stream
+ * when profiling is enabled. names/ms arrays are ctx-owned; returns the number of stages. */
+int dvs_enable_stage_timing(dvs_ctx* ctx, int enable);
+int dvs_get_stage_timing(dvs_ctx* ctx, const char*** names, const float** ms);
+
+/* Synchronous copies between host and device on the ctx's device (test plumbing; no torch needed). */
+int dvs_memcpy_d2h(dvs_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int dvs_memcpy_h2d(dvs_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+void* dvs_device_malloc(dvs_ctx* ctx, size_t bytes);
+void  dvs_device_free(dvs_ctx* ctx, void* p);
+
+const char* dvs_last_error(void);
+const char* dvs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVS_RASTER_H */

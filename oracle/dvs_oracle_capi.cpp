@@ -1,0 +1,94 @@
+// dvs_oracle_capi.cpp — C entry points of the CPU ORACLE for ctypes (test infrastructure only;
+// see the header of dvs_oracle.hpp: PARITY UNPINNED, conventions cited there).
+// Build: make -C oracle   ->  oracle/_build/libdvs_oracle.so
+#include "dvs_oracle.hpp"
+#include <string>
+
+namespace {
+struct Handle {
+    int is_double;
+    dvso::State<float> f;
+    dvso::State<double> d;
+};
+
+template <class T>
+void load_inputs(dvso::State<T>& S, int n, const void* pos, const void* sh0, const void* shN, const void* opacity,
+                 const void* scale, const void* rot, const dvs_camera* cam, const dvs_opts* opts) {
+    S.n = n; S.cam = *cam; S.opts = *opts;
+    auto cp = [&](std::vector<T>& v, const void* p, size_t cnt) { v.assign((const T*)p, (const T*)p + cnt); };
+    cp(S.pos, pos, 3 * (size_t)n); cp(S.sh0, sh0, 3 * (size_t)n); cp(S.shN, shN, 45 * (size_t)n);
+    cp(S.opacity, opacity, n); cp(S.scale, scale, 3 * (size_t)n); cp(S.rot, rot, 4 * (size_t)n);
+}
+
+template <class T>
+const void* get_array(dvso::State<T>& S, const std::string& name, uint64_t* count, int* elem_bytes) {
+#define DVSO_ARR(nm, vec)                                                         \
+    if (name == nm) { *count = (vec).size(); *elem_bytes = (int)sizeof((vec)[0]); return (vec).data(); }
+    DVSO_ARR("radii", S.radii) DVSO_ARR("mean2d", S.mean2d) DVSO_ARR("depth", S.depth)
+    DVSO_ARR("conic_opacity", S.conic_opacity) DVSO_ARR("rgb", S.rgb) DVSO_ARR("flags", S.flags)
+    DVSO_ARR("tiles_touched", S.tiles_touched) DVSO_ARR("rect", S.rect) DVSO_ARR("depth_bits", S.depth_bits)
+    DVSO_ARR("offsets", S.offsets) DVSO_ARR("keys", S.keys) DVSO_ARR("vals", S.vals) DVSO_ARR("ranges", S.ranges)
+    DVSO_ARR("out_color", S.out_color) DVSO_ARR("final_T", S.final_T) DVSO_ARR("n_contrib", S.n_contrib)
+    DVSO_ARR("fragile", S.fragile)
+    DVSO_ARR("dL_dmean2d", S.dL_dmean2d) DVSO_ARR("dL_dconic_opacity", S.dL_dconic_opacity)
+    DVSO_ARR("dL_drgb", S.dL_drgb) DVSO_ARR("absgrad", S.absgrad)
+    DVSO_ARR("g_pos", S.g_pos) DVSO_ARR("g_sh0", S.g_sh0) DVSO_ARR("g_shN", S.g_shN)
+    DVSO_ARR("g_opacity", S.g_opacity) DVSO_ARR("g_scale", S.g_scale) DVSO_ARR("g_rot", S.g_rot)
+#undef DVSO_ARR
+    *count = 0; *elem_bytes = 0;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+void* dvso_create(int use_double) {
+    Handle* h = new Handle();
+    h->is_double = use_double;
+    return h;
+}
+void dvso_destroy(void* hp) { delete (Handle*)hp; }
+
+// Arrays are float (handle created with use_double=0) or double (use_double=1), host memory, A0 layout.
+int dvso_forward(void* hp, int n, const void* pos, const void* sh0, const void* shN, const void* opacity,
+                 const void* scale, const void* rot, const dvs_camera* cam, const dvs_opts* opts) {
+    Handle* h = (Handle*)hp;
+    if (h->is_double) {
+        load_inputs(h->d, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
+        dvso::preprocess_forward(h->d); dvso::bin(h->d); dvso::render_forward(h->d);
+    } else {
+        load_inputs(h->f, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
+        dvso::preprocess_forward(h->f); dvso::bin(h->f); dvso::render_forward(h->f);
+    }
+    return 0;
+}
+
+// dL_dout: [3,H,W] planar, float or double per the handle.
+int dvso_backward(void* hp, const void* dL_dout) {
+    Handle* h = (Handle*)hp;
+    if (h->is_double) { dvso::render_backward(h->d, (const double*)dL_dout); dvso::preprocess_backward(h->d); }
+    else { dvso::render_backward(h->f, (const float*)dL_dout); dvso::preprocess_backward(h->f); }
+    return 0;
+}
+
+const void* dvso_array(void* hp, const char* name, uint64_t* count, int* elem_bytes) {
+    Handle* h = (Handle*)hp;
+    return h->is_double ? get_array(h->d, name, count, elem_bytes) : get_array(h->f, name, count, elem_bytes);
+}
+
+uint64_t dvso_interactions(void* hp) {
+    Handle* h = (Handle*)hp;
+    return h->is_double ? h->d.interactions : h->f.interactions;
+}
+
+// scalar helpers for the known-answer tests
+float dvso_expf(float x) { return dvso::det_expf(x); }
+float dvso_sigmoidf(float x) { return dvso::sigmoid<float>(x); }
+void dvso_sh_basis(int deg, double x, double y, double z, double* b16) { dvso::sh_basis<double>(deg, x, y, z, b16); }
+void dvso_cov3d(const double* scale3 /*already activated*/, const double* quat_wxyz_unit, double* cov6) {
+    double R[9];
+    dvso::quat_to_rot<double>(quat_wxyz_unit[0], quat_wxyz_unit[1], quat_wxyz_unit[2], quat_wxyz_unit[3], R);
+    dvso::cov3d_from_scale_rot<double>(scale3, R, cov6);
+}
+
+}  // extern "C"

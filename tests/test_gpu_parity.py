@@ -1,0 +1,226 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle, through the C-ABI.
+
+Bars: radii / tiles_touched / sorted (key,value) / tile ranges bit-exact; preprocess floats bit-exact
+(same IEEE op order, -ffp-contract=off); RGB, final_T within 1e-4 rel on pixels the oracle does not
+flag as threshold-fragile, n_contrib exact there; the five gradient groups within 1e-4 rel (+1e-6 of the
+group's max as absolute floor for cancelling sums) of the fp64 oracle.
+"""
+import numpy as np
+import pytest
+import divshot_amd as dv
+from util import scene, rel_close, KEYS
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (n, W, H, deg, seed, scale_offset, antialias, bg)
+    "C1_10k_256_deg0": (10_000, 256, 256, 0, 1, 0.0, False, (0, 0, 0)),
+    "G2_2k_64_deg3": (2_000, 64, 64, 3, 1, 0.0, False, (0.3, 0.1, 0.2)),
+    "ragged_5k_250x130_deg2_aa": (5_000, 250, 130, 2, 7, 0.5, True, (0, 0, 0)),
+    "dense_3k_96_big": (3_000, 96, 96, 1, 5, 1.5, False, (1, 1, 1)),
+    "C2_100k_800_deg3": (100_000, 800, 800, 3, 1, 0.0, False, (0, 0, 0)),
+}
+
+
+@pytest.fixture(scope="module")
+def rast(gpu_device):
+    from divshot_amd.raster import Rasterizer
+    r = Rasterizer(0, max_splats=1 << 20, max_w=1920, max_h=1080)
+    yield r
+    r.close()
+
+
+def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
+    import torch
+    from divshot_amd.raster import params_to_device
+    Pd = params_to_device(P, rast.tdev)
+    img = rast.forward(Pd, cam, sh_degree=deg, antialias=aa, absgrad=absgrad)
+    torch.cuda.synchronize()
+    img_h = img.cpu().numpy()
+    saved = rast.saved()
+    keys = rast.sorted_keys()
+    dL = torch.from_numpy((img_h - tgt) / tgt[0].size).to(rast.tdev)
+    grads = rast.backward(dL, want_mean2d=True)
+    torch.cuda.synchronize()
+    inter = rast.bwd_intermediates()
+    return img_h, saved, keys, {k: v.cpu().numpy() for k, v in grads.items()}, inter, (img_h - tgt) / tgt[0].size
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_pipeline_parity(rast, oracle_mod, name):
+    n, W, H, deg, seed, soff, aa, bg = CONFIGS[name]
+    spec, P, cam, tgt = scene(n, W, H, deg, seed, scale_offset=soff, bg=bg)
+    img, saved, keys, grads, inter, dL = _run_gpu(rast, P, cam, tgt, deg, aa)
+
+    o = oracle_mod.Oracle(np.float32)
+    ref_img = o.forward(P, cam, sh_degree=deg, antialias=aa)
+
+    # --- A2 preprocess: integers bit-exact, floats bit-exact -------------------------------------
+    np.testing.assert_array_equal(saved["radii"], o.get("radii"))
+    np.testing.assert_array_equal(saved["tiles_touched"], o.get("tiles_touched"))
+    np.testing.assert_array_equal(saved["flags"], o.get("flags"))
+    for k in ("mean2d", "depth", "conic_opacity", "rgb"):
+        a, b = saved[k], o.get(k).reshape(saved[k].shape)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k}: {(a != b).sum()} of {a.size} floats differ"
+    assert (saved["radii"] > 0).sum() > 0.5 * n
+
+    # --- A3-A6 binning: bit-exact --------------------------------------------------------------------
+    assert keys.shape == o.get("keys").shape
+    np.testing.assert_array_equal(keys, o.get("keys"))
+    np.testing.assert_array_equal(saved["vals"], o.get("vals"))
+    np.testing.assert_array_equal(saved["ranges"], o.get("ranges"))
+    assert rast.num_rendered == o.get("vals").size
+
+    # --- A7 composite forward ----------------------------------------------------------------------------
+    frag = o.get("fragile").astype(bool)
+    assert frag.mean() < 1e-3
+    ok = ~frag
+    nc_ref = o.get("n_contrib")
+    assert np.array_equal(saved["n_contrib"][ok], nc_ref[ok]), f"{(saved['n_contrib'][ok] != nc_ref[ok]).sum()} n_contrib mismatches"
+    m, worst = rel_close(img[:, ok], ref_img[:, ok], 1e-4, 1e-6)
+    assert m.all(), f"rgb worst {worst}"
+    m, worst = rel_close(saved["final_T"][ok], o.get("final_T")[ok], 1e-4, 1e-6)
+    assert m.all(), f"final_T worst {worst}"
+
+    # --- A8/A9 backward vs fp64 oracle driven by the SAME upstream gradient -------------------------------
+    o64 = oracle_mod.Oracle(np.float64)
+    o64.forward(P, cam, sh_degree=deg, antialias=aa)
+    if not np.array_equal(o64.get("n_contrib"), nc_ref) or not np.array_equal(o64.get("vals"), o.get("vals")):
+        # fp64 made a different threshold decision somewhere: fall back to the fp32 oracle as reference
+        o64 = o
+    ref = o64.backward(dL)
+    for k, nm in (("dL_dmean2d", "dL_dmean2d"), ("dL_dconic_opacity", "dL_dconic_opacity"), ("dL_drgb", "dL_drgb")):
+        m, worst = rel_close(inter[k], o64.get(nm), 1e-4, 2e-6)
+        assert m.mean() > 0.9999 and worst < 50, f"{k}: worst {worst}, frac ok {m.mean()}"
+    m, worst = rel_close(grads["absgrad2d"], o64.get("absgrad"), 1e-4, 2e-6)
+    assert m.mean() > 0.9999 and worst < 50, f"absgrad worst {worst}"
+    m, worst = rel_close(grads["mean2d"], o64.get("dL_dmean2d"), 1e-4, 2e-6)
+    assert m.mean() > 0.9999 and worst < 50, f"mean2d worst {worst}"
+    for k in KEYS:
+        m, worst = rel_close(grads[k], ref[k], 1e-4, 2e-6)
+        assert m.mean() > 0.9999 and worst < 50, f"grad {k}: worst {worst}, frac ok {m.mean()}"
+    # culled splats get exactly zero rows
+    culled = saved["radii"] == 0
+    for k in KEYS:
+        assert not np.any(grads[k][culled]), k
+
+
+def test_accumulate_two_views(rast, oracle_mod):
+    """opts.accumulate adds the second view's rows into the first's (multi-view batches)."""
+    import torch
+    from divshot_amd.raster import params_to_device
+    spec = dv.make_spec(4000, 128, 96, sh_degree=3, n_cams=3)
+    P = dv.synth_splats(spec)
+    Pd = params_to_device(P, rast.tdev)
+    total = None
+    acc = None
+    for ci in (0, 2):
+        cam = dv.synth_camera(spec, ci)
+        tgt = dv.synth_target(spec, ci)
+        img = rast.forward(Pd, cam, sh_degree=3)
+        dL = (img - torch.from_numpy(tgt).to(rast.tdev)) / tgt[0].size
+        single = rast.backward(dL.contiguous())
+        if total is None:
+            total = {k: single[k].clone() for k in KEYS}
+            acc = {k: single[k].clone() for k in KEYS}
+        else:
+            for k in KEYS:
+                total[k] += single[k]
+            rast.backward(dL.contiguous(), grads=acc, accumulate=True)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        m, worst = rel_close(acc[k].cpu().numpy(), total[k].cpu().numpy(), 1e-4, 2e-6)
+        assert m.all(), (k, worst)
+
+
+def test_edge_cases(rast, oracle_mod):
+    """empty scene, everything culled, one splat on a tile corner, a splat covering the whole image
+    (wave-cooperative duplication), a pixel stack that saturates (T < 1e-4), tile lists > 256 entries."""
+    import torch
+    from divshot_amd.raster import params_to_device
+    spec = dv.make_spec(0, 80, 48, sh_degree=1)
+    cam = dv.synth_camera(spec, 0)
+    cam.bg[0], cam.bg[1], cam.bg[2] = 0.25, 0.5, 0.75
+
+    def run(P, deg=1):
+        Pd = params_to_device(P, rast.tdev)
+        img = rast.forward(Pd, cam, sh_degree=deg, absgrad=True)
+        torch.cuda.synchronize()
+        o = oracle_mod.Oracle(np.float32)
+        ref = o.forward(P, cam, sh_degree=deg)
+        saved = rast.saved()
+        np.testing.assert_array_equal(saved["radii"], o.get("radii"))
+        np.testing.assert_array_equal(saved["vals"], o.get("vals"))
+        np.testing.assert_array_equal(rast.sorted_keys(), o.get("keys"))
+        np.testing.assert_array_equal(saved["ranges"], o.get("ranges"))
+        ok = ~o.get("fragile").astype(bool)
+        m, worst = rel_close(img.cpu().numpy()[:, ok], ref[:, ok], 1e-4, 1e-6)
+        assert m.all(), worst
+        assert np.array_equal(saved["n_contrib"][ok], o.get("n_contrib")[ok])
+        dLn = np.random.default_rng(0).standard_normal(ref.shape).astype(np.float32)
+        g = rast.backward(torch.from_numpy(dLn).to(rast.tdev))
+        torch.cuda.synchronize()
+        gref = o.backward(dLn)
+        for k in KEYS:
+            m, worst = rel_close(g[k].cpu().numpy(), gref[k], 2e-4, 1e-5)
+            assert m.all(), (k, worst)
+        return img.cpu().numpy(), saved, o
+
+    def mk(n):
+        return {"pos": np.zeros((n, 3), np.float32), "sh0": np.zeros((n, 3), np.float32), "shN": np.zeros((n, 15, 3), np.float32),
+                "opacity": np.zeros((n,), np.float32), "scale": np.full((n, 3), -3.0, np.float32),
+                "rot": np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1))}
+
+    # empty scene -> background
+    img, saved, _ = run(mk(0))
+    assert np.allclose(img[0], 0.25) and np.allclose(img[2], 0.75) and rast.num_rendered == 0
+    # all behind the camera / too near / zero quaternion / transparent
+    P = mk(6); P["pos"][:, 2] = [-5, 0.1, 0.2, 5, 5, 5]; P["rot"][3] = 0; P["opacity"][4] = -20.0; P["pos"][5, 0] = 1e4
+    img, saved, _ = run(P)
+    assert (saved["radii"] == 0).all() and rast.num_rendered == 0
+    # splat centred exactly on a tile corner (pixel centre 15.5 -> between tiles), and one covering everything
+    P = mk(3); P["pos"][:, 2] = 5.0
+    fx = cam.focal_x
+    P["pos"][0, 0] = (15.5 - (80 - 1) / 2) * 5.0 / fx; P["pos"][0, 1] = (15.5 - (48 - 1) / 2) * 5.0 / fx
+    P["scale"][1] = 1.5; P["opacity"][1] = 1.0; P["sh0"][1] = [1.0, -4.0, 0.5]   # huge, green clamps to 0
+    P["pos"][2] = [0.3, -0.2, 3.0]; P["scale"][2] = [-2.0, -1.0, -4.0]; P["rot"][2] = [0.3, -0.8, 0.1, 0.5]
+    img, saved, o = run(P)
+    assert saved["tiles_touched"][1] == 5 * 3 and saved["tiles_touched"][0] == 4
+    assert (o.get("flags")[1] & 2) != 0
+    # saturation + long tile lists: 1500 opaque splats stacked on a few pixels
+    rng = np.random.default_rng(3)
+    P = mk(1500); P["pos"][:, 2] = np.linspace(3, 9, 1500); P["pos"][:, :2] = rng.normal(0, 0.05, (1500, 2))
+    P["opacity"][:] = 3.0; P["scale"][:] = -2.5; P["sh0"][:] = rng.normal(0, 1, (1500, 3))
+    img, saved, o = run(P)
+    r = saved["ranges"]
+    assert (r[:, 1] - r[:, 0]).max() > 256
+    assert (saved["final_T"] < 2e-4).any()
+
+
+def test_sort_pairs(rast):
+    """A5 radix sort alone: stable, LSD, arbitrary sizes and bit ranges (vs numpy stable argsort)."""
+    import torch
+    rng = np.random.default_rng(11)
+    for n, lo, hi in [(0, 0, 32), (1, 0, 32), (63, 0, 32), (2048, 0, 32), (2049, 0, 16), (100_003, 0, 32),
+                      (1_000_000, 0, 32), (300_000, 8, 24), (70_000, 0, 13)]:
+        keys = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+        if n > 10:
+            keys[rng.integers(0, n, n // 3)] = keys[0]        # many duplicates -> stability matters
+        vals = np.arange(n, dtype=np.uint32)
+        k_d = torch.from_numpy(keys.view(np.int32).copy()).to(rast.tdev)
+        v_d = torch.from_numpy(vals.view(np.int32).copy()).to(rast.tdev)
+        rast.sort_pairs(k_d, v_d, lo, hi)
+        torch.cuda.synchronize()
+        mask = np.uint32(((1 << (hi - lo)) - 1) << lo) if hi - lo < 32 else np.uint32(0xFFFFFFFF)
+        order = np.argsort(keys & mask, kind="stable")
+        np.testing.assert_array_equal(k_d.cpu().numpy().view(np.uint32), keys[order])
+        np.testing.assert_array_equal(v_d.cpu().numpy().view(np.uint32), vals[order])
+    # all keys equal, and already-sorted / reverse-sorted inputs
+    for keys in (np.full(5000, 7, np.uint32), np.arange(5000, dtype=np.uint32), np.arange(5000, dtype=np.uint32)[::-1].copy()):
+        vals = np.arange(keys.size, dtype=np.uint32)
+        k_d = torch.from_numpy(keys.view(np.int32).copy()).to(rast.tdev)
+        v_d = torch.from_numpy(vals.view(np.int32).copy()).to(rast.tdev)
+        rast.sort_pairs(k_d, v_d)
+        torch.cuda.synchronize()
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(v_d.cpu().numpy().view(np.uint32), vals[order])
