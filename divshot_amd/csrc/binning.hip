@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 // ---- A5: one LSD pass = histogram, row scan, scatter -----------------------------------------------
 // wave w of block b owns the contiguous items [b*PART + w*512, +512), read in 8 rounds of 64.
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t* __restrict__ hist, uint32_t num_blocks) {
+k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t dmask, uint32_t* __restrict__ hist, uint32_t num_blocks) {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX];
     for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
     __syncthreads();
@@ -67,7 +67,7 @@ k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t* 
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = valid ? ((keys[idx] >> shift) & 0xFFu) : 0u;
+        const uint32_t d = valid ? ((keys[idx] >> shift) & dmask) : 0u;
         const uint64_t peers = match_digit(d, valid);
         if (valid) {
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
@@ -101,7 +101,7 @@ k_sort_rowscan(uint32_t* __restrict__ hist, uint32_t num_blocks, uint32_t* __res
 
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-               uint32_t* __restrict__ vals_out, uint64_t n, int shift, const uint32_t* __restrict__ hist,
+               uint32_t* __restrict__ vals_out, uint64_t n, int shift, uint32_t dmask, const uint32_t* __restrict__ hist,
                const uint32_t* __restrict__ totals, uint32_t num_blocks) {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX];     // per-wave digit counts, then per-wave destination bases
     __shared__ uint32_t tmp[SORT_WAVES + 1];
@@ -121,7 +121,7 @@ k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict_
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = (key[r] >> shift) & 0xFFu;
+        const uint32_t d = (key[r] >> shift) & dmask;
         const uint64_t peers = match_digit(d, valid);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
         uint32_t prev = 0;
@@ -146,7 +146,7 @@ k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict_
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
         if (idx < n) {
-            const uint32_t d = (key[r] >> shift) & 0xFFu;
+            const uint32_t d = (key[r] >> shift) & dmask;
             const uint32_t dst = cnt[wave][d] + rank[r];
             keys_out[dst] = key[r];
             vals_out[dst] = val[r];
@@ -160,15 +160,16 @@ size_t dvs_sort_scratch_words(uint64_t n) {
 }
 
 hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                                uint32_t* vals_out, uint64_t n, int shift, uint32_t* scratch) {
+                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = (uint32_t)((n + SORT_PART - 1) / SORT_PART);
     uint32_t* hist = scratch;
     uint32_t* totals = scratch + (size_t)nb * RADIX;
-    hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, hist, nb);
+    const uint32_t dmask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
+    hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, dmask, hist, nb);
     hipLaunchKernelGGL(k_sort_rowscan, dim3(RADIX), dim3(SORT_BLOCK), 0, st, hist, nb, totals);
     hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
-                       hist, totals, nb);
+                       dmask, hist, totals, nb);
     return hipGetLastError();
 }
 

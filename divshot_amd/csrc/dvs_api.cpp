@@ -210,7 +210,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     int cur = 0;
     for (int pass = 0; pass < 4; ++pass) {
         HIPCHECK(dvs_launch_sort_pass(st, c->key[cur].as<uint32_t>(), c->ids[cur].as<uint32_t>(), c->key[cur ^ 1].as<uint32_t>(),
-                                      c->ids[cur ^ 1].as<uint32_t>(), (uint64_t)n, pass * 8, c->sort_scratch.as<uint32_t>()));
+                                      c->ids[cur ^ 1].as<uint32_t>(), (uint64_t)n, pass * 8, 8, c->sort_scratch.as<uint32_t>()));
         cur ^= 1;
     }
     size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
@@ -236,7 +236,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     for (int shift = 0; shift < tile_bits; shift += 8) {
         HIPCHECK(dvs_launch_sort_pass(st, c->inst_tile[icur].as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                       c->inst_tile[icur ^ 1].as<uint32_t>(), c->inst_splat[icur ^ 1].as<uint32_t>(), T, shift,
-                                      c->sort_scratch.as<uint32_t>()));
+                                      tile_bits - shift, c->sort_scratch.as<uint32_t>()));
         icur ^= 1;
     }
     size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
@@ -269,7 +269,7 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     if (!c->have_fwd || c->st.n != p->n || c->st.width != cam->width || c->st.height != cam->height) {
         g_last_error = "dvs_raster_backward: no matching forward on this context"; return DVS_ERR_STATE;
     }
-    if (!out->pos || !out->sh0 || !out->shN || !out->opacity || !out->scale || !out->rot) {
+    if (p->n > 0 && (!out->pos || !out->sh0 || !out->shN || !out->opacity || !out->scale || !out->rot)) {
         g_last_error = "dvs_raster_backward: null gradient row pointer"; return DVS_ERR_INVALID;
     }
     HIPCHECK(hipSetDevice(c->device));
@@ -304,7 +304,7 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
 }
 
 int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals, uint64_t n, int bit_lo, int bit_hi) {
-    if (!c || !keys || !vals || bit_lo < 0 || bit_hi > 32 || bit_lo > bit_hi) { g_last_error = "dvs_sort_pairs_u32: bad argument"; return DVS_ERR_INVALID; }
+    if (!c || (n > 0 && (!keys || !vals)) || bit_lo < 0 || bit_hi > 32 || bit_lo > bit_hi) { g_last_error = "dvs_sort_pairs_u32: bad argument"; return DVS_ERR_INVALID; }
     HIPCHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return DVS_OK;
@@ -316,7 +316,7 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
     uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
     int cur = 0;
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        HIPCHECK(dvs_launch_sort_pass(st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, shift, c->sort_scratch.as<uint32_t>()));
+        HIPCHECK(dvs_launch_sort_pass(st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, shift, bit_hi - shift, c->sort_scratch.as<uint32_t>()));
         cur ^= 1;
     }
     if (cur == 1) {

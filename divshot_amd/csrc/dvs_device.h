@@ -67,6 +67,9 @@ __device__ __forceinline__ float dvs_exp_det(float x) {
     const int e = (int)n;
     return y * __uint_as_float((uint32_t)(e + 127) << 23);
 }
+// IEEE correctly-rounded sqrt: sqrtf() lowers to v_sqrt_f32 + the +-1 ulp fix-up; __fsqrt_rn() on
+// ROCm 7.2 is the raw 1-ulp v_sqrt_f32 and breaks bit-exactness against the CPU oracle.
+__device__ __forceinline__ float dvs_sqrt_rn(float x) { return sqrtf(x); }
 __device__ __forceinline__ float dvs_sigmoid_det(float x) { return 1.0f / (1.0f + dvs_exp_det(-x)); }
 
 __device__ __forceinline__ float dvs_xform(const float* m, float x, float y, float z, int r) {

@@ -19,9 +19,9 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort_pass needs for n items.
 size_t dvs_sort_scratch_words(uint64_t n);
-// One stable LSD pass (8-bit digit at `shift`) of (key,val) pairs: in -> out. n is read on the host.
+// One stable LSD pass (digit = `bits` (<= 8) key bits at `shift`) of (key,val) pairs: in -> out.
 hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                                uint32_t* vals_out, uint64_t n, int shift, uint32_t* scratch);
+                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch);
 // A3: offsets over tiles_touched in depth-sorted order. Writes block offsets and the total (device + pinned host).
 size_t dvs_scan_scratch_words(int n);
 hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,

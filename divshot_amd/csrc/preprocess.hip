@@ -98,7 +98,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         for (int k = 0; k < 3; ++k) s[k] = dvs_exp_det(scale[3 * (int64_t)i + k]);
         const float4 q4 = reinterpret_cast<const float4*>(rot)[i];
         const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
-        const float qn = __fsqrt_rn(((qr * qr + qx * qx) + qy * qy) + qz * qz);
+        const float qn = dvs_sqrt_rn(((qr * qr + qx * qx) + qy * qy) + qz * qz);
         if (!(qn > 0.f)) break;
         const float inv_qn = 1.0f / qn;
         float R[9];
@@ -138,14 +138,14 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         float opac = dvs_sigmoid_det(opacity[i]);
         if (antialias) {
             const float det_orig = cxx * cyy - b * b;
-            const float aa = __fsqrt_rn(fmaxf(0.f, det_orig / det));
+            const float aa = dvs_sqrt_rn(fmaxf(0.f, det_orig / det));
             opac = opac * aa;
         }
         if (!(opac > DVS_ALPHA_MIN)) break;
         const float det_inv = 1.0f / det;
         const float mid = 0.5f * (a + c);
-        const float lam = mid + __fsqrt_rn(fmaxf(0.1f, mid * mid - det));
-        const float radf = ceilf(3.0f * __fsqrt_rn(lam));
+        const float lam = mid + dvs_sqrt_rn(fmaxf(0.1f, mid * mid - det));
+        const float radf = ceilf(3.0f * dvs_sqrt_rn(lam));
         const float m2x = ((ndc_x + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
         const float m2y = ((ndc_y + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
         const float gx = (float)tiles_x, gy = (float)tiles_y, inv_tile = 1.0f / DVS_TILE;
@@ -157,7 +157,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         if (touched <= 0) break;
 
         const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
-        const float dl = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+        const float dl = dvs_sqrt_rn((dx * dx + dy * dy) + dz * dz);
         const float inv_dl = 1.0f / dl;
         float bas[16];
         dvs_sh_basis(deg, dx * inv_dl, dy * inv_dl, dz * inv_dl, bas);
@@ -228,7 +228,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 3; ++k) s[k] = dvs_exp_det(scale[3 * (int64_t)i + k]);
         const float4 q4 = reinterpret_cast<const float4*>(rot)[i];
-        const float qn = __fsqrt_rn(((q4.x * q4.x + q4.y * q4.y) + q4.z * q4.z) + q4.w * q4.w);
+        const float qn = dvs_sqrt_rn(((q4.x * q4.x + q4.y * q4.y) + q4.z * q4.z) + q4.w * q4.w);
         const float inv_qn = 1.0f / qn;
         const float qr = q4.x * inv_qn, qx = q4.y * inv_qn, qy = q4.z * inv_qn, qz = q4.w * inv_qn;
         float R[9];
@@ -261,7 +261,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 
         // 1. colour / SH
         const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
-        const float dl = __fsqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+        const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
         const float inv_dl = 1.0f / dl;
         const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
         float bas[16], dbas[16][3];
@@ -297,7 +297,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         if (antialias) {
             const float det_orig = cxx * cyy - b * b;
             const float ratio = det_orig / det;
-            const float aa = __fsqrt_rn(fmaxf(0.f, ratio));
+            const float aa = dvs_sqrt_rn(fmaxf(0.f, ratio));
             g_sig = gco.w * aa;
             if (ratio > 0.f) {
                 const float g_aa = gco.w * sig;

@@ -2,8 +2,10 @@
 
 Bars: radii / tiles_touched / sorted (key,value) / tile ranges bit-exact; preprocess floats bit-exact
 (same IEEE op order, -ffp-contract=off); RGB, final_T within 1e-4 rel on pixels the oracle does not
-flag as threshold-fragile, n_contrib exact there; the five gradient groups within 1e-4 rel (+1e-6 of the
-group's max as absolute floor for cancelling sums) of the fp64 oracle.
+flag as threshold-fragile, n_contrib exact there; the five gradient groups (and the A8 intermediates)
+against the fp64 oracle: every element within 1e-4 rel + 1e-5 of the group's max |value| (absolute floor
+for sums that cancel: a per-splat gradient is a sum of hundreds of signed per-pixel terms accumulated in
+fp32), and the whole group within 1e-5 relative L2 error.
 """
 import numpy as np
 import pytest
@@ -83,22 +85,42 @@ def test_pipeline_parity(rast, oracle_mod, name):
     assert m.all(), f"final_T worst {worst}"
 
     # --- A8/A9 backward vs fp64 oracle driven by the SAME upstream gradient -------------------------------
+    # A threshold decision (alpha < 1/255, T < 1e-4) that falls within rounding distance of its threshold can
+    # go differently in fp32 and fp64; every splat whose footprint holds such a "fragile" pixel is "tainted"
+    # and is compared with the fp32 oracle (same decisions as the GPU) instead of the fp64 one.
     o64 = oracle_mod.Oracle(np.float64)
     o64.forward(P, cam, sh_degree=deg, antialias=aa)
-    if not np.array_equal(o64.get("n_contrib"), nc_ref) or not np.array_equal(o64.get("vals"), o.get("vals")):
-        # fp64 made a different threshold decision somewhere: fall back to the fp32 oracle as reference
-        o64 = o
-    ref = o64.backward(dL)
-    for k, nm in (("dL_dmean2d", "dL_dmean2d"), ("dL_dconic_opacity", "dL_dconic_opacity"), ("dL_drgb", "dL_drgb")):
-        m, worst = rel_close(inter[k], o64.get(nm), 1e-4, 2e-6)
-        assert m.mean() > 0.9999 and worst < 50, f"{k}: worst {worst}, frac ok {m.mean()}"
-    m, worst = rel_close(grads["absgrad2d"], o64.get("absgrad"), 1e-4, 2e-6)
-    assert m.mean() > 0.9999 and worst < 50, f"absgrad worst {worst}"
-    m, worst = rel_close(grads["mean2d"], o64.get("dL_dmean2d"), 1e-4, 2e-6)
-    assert m.mean() > 0.9999 and worst < 50, f"mean2d worst {worst}"
+    frag_any = frag | o64.get("fragile").astype(bool)
+    tainted = np.zeros(n, bool)
+    fy, fx = np.where(frag_any)
+    m2, rad = saved["mean2d"], saved["radii"]
+    for x, y in zip(fx, fy):
+        tainted |= (np.abs(m2[:, 0] - x) <= rad) & (np.abs(m2[:, 1] - y) <= rad) & (rad > 0)
+    if not name.startswith("dense"):      # huge splats: one fragile pixel taints everything that covers it
+        assert tainted.mean() < 0.10, tainted.mean()
+    if not np.array_equal(o64.get("n_contrib")[~frag_any], nc_ref[~frag_any]) or not np.array_equal(o64.get("vals"), o.get("vals")):
+        tainted[:] = True      # fp64 binned differently (radius at an integer boundary): fp32 oracle everywhere
+    ref64 = o64.backward(dL)
+    ref32 = o.backward(dL)
+
+    def mix(name64, a64, a32):
+        out = np.array(a64, np.float64)
+        out[tainted] = a32[tainted]
+        return out
+
+    def check_group(name, got, want):
+        m, worst = rel_close(got, want, 1e-4, 1e-5)
+        assert m.all(), f"{name}: worst {worst}, frac ok {m.mean()}"
+        g64, w64 = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+        l2 = np.linalg.norm(g64 - w64) / max(np.linalg.norm(w64), 1e-300)
+        assert l2 < 1e-5, f"{name}: relative L2 error {l2}"
+
+    for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb"):
+        check_group(k, inter[k], mix(k, o64.get(k), o.get(k)))
+    check_group("absgrad", grads["absgrad2d"], mix("absgrad", o64.get("absgrad"), o.get("absgrad")))
+    check_group("mean2d", grads["mean2d"], mix("mean2d", o64.get("dL_dmean2d"), o.get("dL_dmean2d")))
     for k in KEYS:
-        m, worst = rel_close(grads[k], ref[k], 1e-4, 2e-6)
-        assert m.mean() > 0.9999 and worst < 50, f"grad {k}: worst {worst}, frac ok {m.mean()}"
+        check_group("grad " + k, grads[k], mix(k, ref64[k], ref32[k]))
     # culled splats get exactly zero rows
     culled = saved["radii"] == 0
     for k in KEYS:
