@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — train views/s (fwd+bwd raster) at 1M splats, 1920x1080, SH degree 3, on 1/2/4/8 MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
+A step = one pass of the hot path over one batch: every rank renders ONE synthetic view of the
+replicated 1M-splat scene (A2..A7), forms dL/drgb = (rgb - target)/P, runs the backward (A8, A9) and,
+for N>1, sum-all-reduces the 59-float gradient rows over xGMI.  value = N*K / time.
+Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n, W, H, sh_degree, scale_log_offset)
+    "C3": (1_000_000, 1920, 1080, 3, 0.0),     # BASELINE.json configs[2] / metric config
+    "C2": (100_000, 800, 800, 3, 0.0),
+    "C1": (10_000, 256, 256, 0, 0.0),
+    "C5": (5_000_000, 3840, 2160, 3, -math.log(2.0)),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(N, V, T, P, tiles, sh_degree, absgrad):
+    """SURVEY.md §8(d) 'Algorithmic bytes per view', per stage."""
+    K = (sh_degree + 1) ** 2
+    B_sh = 12 * K
+    p = math.ceil((32 + math.ceil(math.log2(max(tiles, 2)))) / 8)
+    return {
+        "preprocess_fwd": 44 * N + (B_sh + 48) * V + 8 * (N - V),
+        "tile_scan": 8 * N,
+        "duplicate": 20 * V + 12 * T,
+        "sort": (8 + 24 * p) * T,
+        "tile_ranges": 8 * T + 8 * tiles,
+        "render_fwd": 40 * T + 20 * P,
+        "render_bwd": 76 * T + 20 * P + (8 * T if absgrad else 0),
+        "preprocess_bwd": (44 + B_sh + 36 + 48) * V + (44 + B_sh) * N,
+    }, p
+
+
+def cpu_baseline(workload, max_seconds=60.0):
+    """The CPU oracle (kind 'port': the reference's CPU libtorch path is not in its tree)
+    timed on this box's host cores: one fwd+bwd view of the bench workload, all cores (OpenMP)."""
+    import numpy as np
+    import divshot_amd as dv
+    from oracle import Oracle
+    n, W, H, deg, soff = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
+    # probe on a 1/16 sample of the splats at full resolution to bound the wall time
+    frac = 1.0
+    spec = dv.make_spec(n // 16, W, H, sh_degree=deg, scale_log_offset=soff)
+    o = Oracle(np.float32)
+    P = dv.synth_splats(spec); cam = dv.synth_camera(spec, 0); tgt = dv.synth_target(spec, 0)
+    t0 = time.perf_counter(); img = o.forward(P, cam, sh_degree=deg); o.backward((img - tgt) / tgt[0].size)
+    probe = time.perf_counter() - t0
+    if probe * 16 > max_seconds:
+        frac = 1.0 / 16
+        secs, sample = probe, f"{workload} with 1/16 of the splats ({n // 16}) at {W}x{H}, 1 view fwd+bwd, OpenMP {cores} threads (full size predicted > {max_seconds:.0f}s)"
+    else:
+        spec = dv.make_spec(n, W, H, sh_degree=deg, scale_log_offset=soff)
+        P = dv.synth_splats(spec); cam = dv.synth_camera(spec, 0); tgt = dv.synth_target(spec, 0)
+        t0 = time.perf_counter(); img = o.forward(P, cam, sh_degree=deg); o.backward((img - tgt) / tgt[0].size)
+        secs = time.perf_counter() - t0
+        sample = f"{workload} full ({n} splats, {W}x{H}, SH{deg}), 1 view fwd+bwd, OpenMP {cores} threads"
+    return {"value": 1.0 / secs, "unit": "views/s (of the sample)", "cores": cores, "kind": "port",
+            "sample": sample, "seconds": secs, "sample_fraction_of_splats": frac}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
+    ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import divshot_amd as dv
+    from divshot_amd.raster import Rasterizer, params_to_device, PARAM_KEYS, PARAM_WIDTH
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n, W, H, deg, soff = WORKLOADS[args.workload]
+    n_cams = max(8, world)
+    spec = dv.make_spec(n, W, H, sh_degree=deg, n_cams=n_cams, scale_log_offset=soff)
+    P = dv.synth_splats(spec)                     # identical replica on every rank (same seed)
+    cam = dv.synth_camera(spec, rank % n_cams)    # rank r renders view r
+    target = torch.from_numpy(dv.synth_target(spec, rank % n_cams)).to(dev)
+    params = params_to_device(P, dev)
+    rast = Rasterizer(local_rank, max_splats=n, max_w=W, max_h=H)
+    # one flat gradient buffer so the exchange is a single large collective (236 B/splat)
+    flat = torch.zeros(n * 59, dtype=torch.float32, device=dev)
+    grads, off = {}, 0
+    for k in PARAM_KEYS:
+        w = PARAM_WIDTH[k]
+        grads[k] = flat[off:off + n * w].view(params[k].shape)
+        off += n * w
+    if args.absgrad:
+        grads["absgrad2d"] = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    inv_P = 1.0 / (W * H)
+
+    def step():
+        img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out)
+        dL = (img - target) * inv_P
+        rast.backward(dL, grads=grads)
+        if dist is not None:
+            dist.all_reduce(flat)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-stage hipEvent timing (separate iterations; timing mode synchronises per call) --------------
+    stage_ms = {}
+    if rank == 0 and args.profile_iters > 0:
+        rast.enable_timing(True)
+        acc = {}
+        for _ in range(args.profile_iters):
+            img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out)
+            dL = (img - target) * inv_P
+            rast.backward(dL, grads=grads)
+            for k, v in rast.stage_timing().items():
+                acc.setdefault(k, []).append(v)
+        rast.enable_timing(False)
+        stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        st = rast.state
+        V = int((torch.from_numpy(rast._d2h(st.radii, (n,), np.int32)) > 0).sum())
+        T = int(st.num_rendered)
+        Ppix = W * H
+        tiles = st.tiles_x * st.tiles_y
+        ab, p = algorithmic_bytes(n, V, T, Ppix, tiles, deg, bool(args.absgrad))
+        total_bytes = sum(ab.values())
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        # dominant kernel = the longest single-kernel stage
+        single = {k: stage_ms[k] for k in ("render_bwd", "render_fwd", "preprocess_fwd", "preprocess_bwd", "duplicate") if k in stage_ms}
+        roofline = None
+        if single:
+            dom = max(single, key=single.get)
+            achieved = ab[dom] / (single[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": single[dom]}
+        stage_table = {}
+        for k, v in stage_ms.items():
+            stage_table[k] = {"ms": v}
+        if "depth_sort" in stage_ms and "tile_sort" in stage_ms:
+            stage_table["sort_total"] = {"ms": stage_ms["depth_sort"] + stage_ms["tile_sort"], "algorithmic_bytes": ab["sort"]}
+        for k in ab:
+            if k in stage_table:
+                stage_table[k]["algorithmic_bytes"] = ab[k]
+        raster_ms = sum(v for k, v in stage_ms.items()) if stage_ms else None
+        rec = {
+            "metric": "train views/sec (fwd+bwd raster) at 1M splats 1920x1080" if args.workload == "C3" else f"train views/sec (fwd+bwd raster), workload {args.workload}",
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, 1 view per GPU per step"
+                                   + (", RCCL all-reduce of 59-float gradient rows" if world > 1 else ""),
+                       "views_per_step": world, "absgrad": bool(args.absgrad),
+                       "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
+            "roofline": roofline,
+            "pipeline": {"algorithmic_bytes_per_view": total_bytes,
+                         "achieved_GBps_end_to_end": total_bytes / (ms_per_step * 1e-3) / 1e9 if world == 1 else None,
+                         "frac_of_hbm_peak_end_to_end": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
+                         "sum_of_stage_ms": raster_ms, "stages": stage_table},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                rec["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as e:      # the oracle is test infrastructure; its absence must not hide the GPU number
+                rec["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(rec), flush=True)
+    rast.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
