@@ -10,7 +10,7 @@
 //                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 64 B/splat
 //   per instance: tile u32 x2 | splat u32 x2 (ping-pong)                                              = 16 B/instance
 //   per tile    : range u32x2          per pixel: final_T f32, n_contrib u32
-//   backward    : dL_dmean2d f32x2 | dL_dconic_opacity f32x4 | dL_drgb f32x3 | absgrad f32x2        = 44 B/splat
+//   backward    : one 48-B gradient row per splat: dL_d{mean2d x2, conic x3, opacity, rgb x3}, |dL_dmean2d| x2, pad
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -68,7 +68,7 @@ struct dvs_ctx {
     Buf inst_tile[2], inst_splat[2];
     Buf sort_scratch, tmp_keys, tmp_vals;
     Buf ranges, final_T, n_contrib;
-    Buf g_mean2d, g_conic_opacity, g_rgb, g_absgrad;
+    Buf g_rows;
     uint64_t* total_dev = nullptr;
     uint64_t* total_host = nullptr;      // pinned
     dvs_fwd_state st{};
@@ -114,7 +114,7 @@ int ensure_splat_arenas(dvs_ctx* c, size_t n) {
     ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
     ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
     ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)
-    ENS(g_mean2d, n * 8) ENS(g_conic_opacity, n * 16) ENS(g_rgb, n * 12) ENS(g_absgrad, n * 8)
+    ENS(g_rows, n * 48)
 #undef ENS
     return DVS_OK;
 }
@@ -171,8 +171,7 @@ void dvs_destroy(dvs_ctx* c) {
     (void)hipSetDevice(c->device);
     Buf* all[] = {&c->radii, &c->mean2d, &c->depth, &c->conic_opacity, &c->rgb, &c->flags, &c->tiles_touched, &c->key[0], &c->key[1],
                   &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
-                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_mean2d,
-                  &c->g_conic_opacity, &c->g_rgb, &c->g_absgrad};
+                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows};
     for (Buf* b : all) b->release();
     if (c->total_dev) (void)hipFree(c->total_dev);
     if (c->total_host) (void)hipHostFree(c->total_host);
@@ -280,24 +279,18 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     timing_reset(c);
     StageTimer tm(c, st);
     size_t e0 = tm.mark();
-    HIPCHECK(hipMemsetAsync(c->g_mean2d.p, 0, (size_t)n * 8, st));
-    HIPCHECK(hipMemsetAsync(c->g_conic_opacity.p, 0, (size_t)n * 16, st));
-    HIPCHECK(hipMemsetAsync(c->g_rgb.p, 0, (size_t)n * 12, st));
-    float* absg = nullptr;
-    if (opts->absgrad) { HIPCHECK(hipMemsetAsync(c->g_absgrad.p, 0, (size_t)n * 8, st)); absg = c->g_absgrad.as<float>(); }
+    HIPCHECK(hipMemsetAsync(c->g_rows.p, 0, (size_t)n * 48, st));
     size_t e1 = tm.mark(); tm.span("bwd_zero", e0, e1);
     HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.mean2d, s.conic_opacity,
-                                   s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_mean2d.as<float>(),
-                                   c->g_conic_opacity.as<float>(), c->g_rgb.as<float>(), absg));
+                                   s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
     size_t e2 = tm.mark(); tm.span("render_bwd", e1, e2);
-    HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
-                                       s.radii, s.flags, c->g_mean2d.as<float>(), c->g_conic_opacity.as<float>(), c->g_rgb.as<float>(),
-                                       out->pos, out->sh0, out->shN, out->opacity, out->scale, out->rot, opts->accumulate));
-    if (out->absgrad2d && absg) {
-        if (opts->accumulate) { g_last_error = "dvs_raster_backward: absgrad2d with accumulate is not supported"; return DVS_ERR_INVALID; }
-        HIPCHECK(hipMemcpyAsync(out->absgrad2d, absg, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    if (out->absgrad2d && opts->absgrad && opts->accumulate) {
+        g_last_error = "dvs_raster_backward: absgrad2d with accumulate is not supported"; return DVS_ERR_INVALID;
     }
-    if (out->mean2d) HIPCHECK(hipMemcpyAsync(out->mean2d, c->g_mean2d.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
+                                       s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
+                                       out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d,
+                                       opts->accumulate));
     size_t e3 = tm.mark(); tm.span("preprocess_bwd", e2, e3);
     if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, true); }
     return DVS_OK;
@@ -334,11 +327,10 @@ int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
     return DVS_OK;
 }
 
-int dvs_get_bwd_intermediates(dvs_ctx* c, const float** m, const float** co, const float** rgb) {
+int dvs_get_bwd_intermediates(dvs_ctx* c, const float** rows, int* row_floats) {
     if (!c) return DVS_ERR_INVALID;
-    if (m) *m = c->g_mean2d.as<float>();
-    if (co) *co = c->g_conic_opacity.as<float>();
-    if (rgb) *rgb = c->g_rgb.as<float>();
+    if (rows) *rows = c->g_rows.as<float>();
+    if (row_floats) *row_floats = 12;
     return DVS_OK;
 }
 

@@ -12,9 +12,10 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
-                                     const int* radii, const uint32_t* flags, const float* dL_dmean2d,
-                                     const float* dL_dconic_opacity, const float* dL_drgb, float* g_pos, float* g_sh0,
-                                     float* g_shN, float* g_opacity, float* g_scale, float* g_rot, int accumulate);
+                                     const int* radii, const uint32_t* flags, const float* grad_rows /*[n,12]*/,
+                                     float* g_pos, float* g_sh0, float* g_shN, float* g_opacity, float* g_scale,
+                                     float* g_rot, float* out_absgrad2d /*nullable*/, float* out_mean2d /*nullable*/,
+                                     int accumulate);
 
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort_pass needs for n items.
@@ -44,5 +45,4 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
                                  const float* rgb, const float bg[3], const float* final_T, const uint32_t* n_contrib,
-                                 const float* dL_dout, float* dL_dmean2d, float* dL_dconic_opacity, float* dL_drgb,
-                                 float* absgrad /*nullable*/);
+                                 const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad);

@@ -197,10 +197,10 @@ __global__ void __launch_bounds__(PP_BLOCK)
 k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
                  const float* __restrict__ scale, const float* __restrict__ rot, DvsCam cam, int deg, int antialias,
                  const int* __restrict__ radii, const uint32_t* __restrict__ flags,
-                 const float2* __restrict__ dL_dmean2d, const float4* __restrict__ dL_dconic_opacity,
-                 const float* __restrict__ dL_drgb,
+                 const float4* __restrict__ grad_rows /*[n,3] float4: mx my ca cb | cc op r g | b |mx| |my| pad*/,
                  float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
-                 float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot) {
+                 float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
+                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
@@ -214,7 +214,12 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     float g_op = 0.f;
     float* row = lds + threadIdx.x * 45;
 
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     if (radius > 0) {
+        r0 = grad_rows[3 * (int64_t)i]; r1 = grad_rows[3 * (int64_t)i + 1]; r2 = grad_rows[3 * (int64_t)i + 2];
+        const float2 dL_dm = make_float2(r0.x, r0.y);
+        const float4 gco = make_float4(r0.z, r0.w, r1.x, r1.y);
+        const float dL_dcol[3] = {r1.z, r1.w, r2.x};
         const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
         const uint32_t fl = flags[i];
         const float tx = dvs_xform(cam.view, px, py, pz, 0);
@@ -272,7 +277,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         float gc[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            gc[ch] = (fl & (1u << ch)) ? 0.f : dL_drgb[3 * (int64_t)i + ch];
+            gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch];
             gs0[ch] = bas[0] * gc[ch];
         }
         for (int k = 1; k < ncoef; ++k) {
@@ -291,7 +296,6 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 
         // 2. opacity (+ AA)
         float g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f;
-        const float4 gco = dL_dconic_opacity[i];
         const float sig = dvs_sigmoid_det(opacity[i]);
         float g_sig = gco.w;
         if (antialias) {
@@ -351,7 +355,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
             gp[k] += (cam.view[k * 4 + 0] * g_tx + cam.view[k * 4 + 1] * g_ty) + cam.view[k * 4 + 2] * g_tz;
         // 6. mean2D
         {
-            const float2 gm = dL_dmean2d[i];
+            const float2 gm = dL_dm;
             const float g_hx = gm.x * 0.5f * (float)cam.width * pw, g_hy = gm.y * 0.5f * (float)cam.height * pw;
             const float g_hw = -(gm.x * 0.5f * (float)cam.width * hx + gm.y * 0.5f * (float)cam.height * hy) * pw * pw;
 #pragma unroll
@@ -395,6 +399,8 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     }
 
     if (valid) {
+        if (out_absgrad2d) out_absgrad2d[i] = make_float2(r2.y, r2.z);
+        if (out_mean2d) out_mean2d[i] = make_float2(r0.x, r0.y);
         const int64_t i3 = 3 * (int64_t)i;
         if (ACCUM) {
             g_pos[i3] += gp[0]; g_pos[i3 + 1] += gp[1]; g_pos[i3 + 2] += gp[2];
@@ -437,19 +443,19 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
 
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
-                                     const int* radii, const uint32_t* flags, const float* dL_dmean2d,
-                                     const float* dL_dconic_opacity, const float* dL_drgb, float* g_pos, float* g_sh0,
-                                     float* g_shN, float* g_opacity, float* g_scale, float* g_rot, int accumulate) {
+                                     const int* radii, const uint32_t* flags, const float* grad_rows, float* g_pos,
+                                     float* g_sh0, float* g_shN, float* g_opacity, float* g_scale, float* g_rot,
+                                     float* out_absgrad2d, float* out_mean2d, int accumulate) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = (size_t)PP_BLOCK * 45 * sizeof(float);
     if (accumulate)
         hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
-                           deg, antialias, radii, flags, (const float2*)dL_dmean2d, (const float4*)dL_dconic_opacity, dL_drgb,
-                           g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot);
+                           deg, antialias, radii, flags, (const float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,
+                           (float2*)out_absgrad2d, (float2*)out_mean2d);
     else
         hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
-                           deg, antialias, radii, flags, (const float2*)dL_dmean2d, (const float4*)dL_dconic_opacity, dL_drgb,
-                           g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot);
+                           deg, antialias, radii, flags, (const float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,
+                           (float2*)out_absgrad2d, (float2*)out_mean2d);
     return hipGetLastError();
 }

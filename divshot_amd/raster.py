@@ -129,12 +129,12 @@ class Rasterizer:
         return buf[:T].cpu().numpy().view(np.uint64)
 
     def bwd_intermediates(self):
-        m, co, rgb = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        check(lib.dvs_get_bwd_intermediates(self.ctx, C.byref(m), C.byref(co), C.byref(rgb)))
+        rows, width = C.c_void_p(), C.c_int(0)
+        check(lib.dvs_get_bwd_intermediates(self.ctx, C.byref(rows), C.byref(width)))
         n = self.state.n
-        return {"dL_dmean2d": self._d2h(m.value, (n, 2), np.float32),
-                "dL_dconic_opacity": self._d2h(co.value, (n, 4), np.float32),
-                "dL_drgb": self._d2h(rgb.value, (n, 3), np.float32)}
+        r = self._d2h(rows.value, (n, width.value), np.float32)
+        return {"dL_dmean2d": r[:, 0:2].copy(), "dL_dconic_opacity": r[:, 2:6].copy(), "dL_drgb": r[:, 6:9].copy(),
+                "absgrad": r[:, 9:11].copy()}
 
     def sort_pairs(self, keys, vals, bit_lo=0, bit_hi=32):
         """In-place stable LSD radix sort of CUDA uint32-as-int32 tensors."""

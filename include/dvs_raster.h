@@ -147,9 +147,9 @@ int dvs_sort_pairs_u32(dvs_ctx* ctx, void* stream, uint32_t* keys, uint32_t* val
  * DEVICE out_keys[T] (parity tests compare them bit-exactly with the oracle's stable_sort). */
 int dvs_export_sorted_keys(dvs_ctx* ctx, void* stream, uint64_t* out_keys);
 
-/* Intermediate gradients of the last backward (DEVICE, ctx-owned): dL/d{mean2D[n,2], conic[n,3]+opacity[n] packed
- * as [n,4], rgb[n,3]} — for stage-level parity of A8. */
-int dvs_get_bwd_intermediates(dvs_ctx* ctx, const float** dL_dmean2d, const float** dL_dconic_opacity, const float** dL_drgb);
+/* Intermediate gradients of the last backward (A8 output; DEVICE, ctx-owned): one row of *row_floats (=12) fp32 per
+ * splat: dL/dmean2D x,y | dL/dconic a,b,c | dL/dopacity | dL/drgb r,g,b | sum|dL/dmean2D| x,y | pad — for stage-level parity. */
+int dvs_get_bwd_intermediates(dvs_ctx* ctx, const float** rows, int* row_floats);
 
 /* Per-stage GPU time (ms) of the last forward/backward, measured with hipEvents on the caller's stream
  * when profiling is enabled. names/ms arrays are ctx-owned; returns the number of stages. */
