@@ -267,7 +267,8 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 for (int e = 0; e < 12; ++e) v[e] = 0.f;
                 if (contrib) {
                     const float4 c = L.rgb[j];
-                    T = T / (1.f - alpha);
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);     // 1-alpha >= 0.01: v_rcp_f32 (1 ulp) is ample
+                    T = T * inv_1ma;
                     const float dchannel_dcolor = alpha * T;
                     acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
                     acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
@@ -277,7 +278,7 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                     v[6] = dchannel_dcolor * dLp0; v[7] = dchannel_dcolor * dLp1; v[8] = dchannel_dcolor * dLp2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    dL_dalpha -= T_final * inv_1ma * bg_dot;
                     if (!(oa > DVS_ALPHA_MAX)) {
                         const float dL_dG = co.w * dL_dalpha;
                         const float gdx = G * dx, gdy = G * dy;

@@ -26,8 +26,8 @@ def main():
         print(f"  {short(r[0])[:52]:52s} {r[1]:6d} {r[2] / 1e3:12.1f} {r[3] / 1e3:10.2f} {r[4] / 1e3:10.2f} {r[5] / 1e3:10.2f} {100 * r[2] / total:6.2f} "
               f"{r[6]:9d} {r[7]:5d} {r[8]:6d} {r[9]:5d} {r[10]:5d} {r[11]:5d}")
     try:
-        pmc = c.execute("select k.name, p.counter_name, sum(p.value), count(*) from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
-                        "group by k.name, p.counter_name order by k.name").fetchall()
+        pmc = c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                        "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
     except sqlite3.Error:
         pmc = []
     if pmc:
