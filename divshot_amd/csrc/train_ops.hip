@@ -1,0 +1,101 @@
+// train_ops.hip — image loss gradient and fused Adam (include/dvs_train.h): HBM-streaming, 16 B per lane.
+// These are SURVEY.md §8(f) "next" rows 2-3, kept minimal; the reference's versions are in the closed plugin.
+#include <hip/hip_runtime.h>
+#include "../../include/dvs_train.h"
+#include "../../include/dvs_raster.h"
+
+#define TB 256
+
+__device__ __forceinline__ float block_sum(float v, float* tmp) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return tmp[0] + tmp[1] + tmp[2] + tmp[3];
+}
+
+template <bool L1>
+__global__ void __launch_bounds__(TB)
+k_loss_grad(const float* __restrict__ rgb, const float* __restrict__ target, size_t count, float scale, float* __restrict__ dL,
+            float* __restrict__ loss_accum) {
+    __shared__ float tmp[4];
+    float local = 0.f;
+    const size_t nvec = count >> 2;
+    for (size_t v = (size_t)blockIdx.x * TB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TB) {
+        const float4 a = reinterpret_cast<const float4*>(rgb)[v], b = reinterpret_cast<const float4*>(target)[v];
+        float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w), g;
+        if (L1) {
+            local += fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + fabsf(d.w);
+            g = make_float4(d.x > 0.f ? scale : (d.x < 0.f ? -scale : 0.f), d.y > 0.f ? scale : (d.y < 0.f ? -scale : 0.f),
+                            d.z > 0.f ? scale : (d.z < 0.f ? -scale : 0.f), d.w > 0.f ? scale : (d.w < 0.f ? -scale : 0.f));
+        } else {
+            local += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+            g = make_float4(d.x * scale, d.y * scale, d.z * scale, d.w * scale);
+        }
+        reinterpret_cast<float4*>(dL)[v] = g;
+    }
+    if (blockIdx.x == 0)
+        for (size_t e = (nvec << 2) + threadIdx.x; e < count; e += TB) {
+            const float d = rgb[e] - target[e];
+            local += L1 ? fabsf(d) : d * d;
+            dL[e] = L1 ? (d > 0.f ? scale : (d < 0.f ? -scale : 0.f)) : d * scale;
+        }
+    const float s = block_sum(local, tmp);
+    if (threadIdx.x == 0 && loss_accum) atomicAdd(loss_accum, L1 ? s * scale : 0.5f * s * scale);
+}
+
+__global__ void __launch_bounds__(TB)
+k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t count, float lr,
+       float b1, float b2, float eps, float bc1, float bc2) {
+    const size_t nvec = count >> 2;
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < nvec; i += (size_t)gridDim.x * TB) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+#define DVS_ADAM1(c)                                                   \
+        mm.c = b1 * mm.c + (1.f - b1) * gg.c;                          \
+        vv.c = b2 * vv.c + (1.f - b2) * gg.c * gg.c;                   \
+        pp.c -= lr * (mm.c * bc1) / (sqrtf(vv.c * bc2) + eps);
+        DVS_ADAM1(x) DVS_ADAM1(y) DVS_ADAM1(z) DVS_ADAM1(w)
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (size_t e = (nvec << 2) + threadIdx.x; e < count; e += TB) {
+            const float ge = g[e];
+            const float me = b1 * m[e] + (1.f - b1) * ge, ve = b2 * v[e] + (1.f - b2) * ge * ge;
+            m[e] = me; v[e] = ve;
+            p[e] -= lr * (me * bc1) / (sqrtf(ve * bc2) + eps);
+        }
+}
+
+static int grid_for(size_t count) {
+    size_t b = (count / 4 + TB - 1) / TB;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;          // 256 CUs x 8 workgroups, grid-stride the rest
+    return (int)b;
+}
+
+extern "C" {
+int dvs_l1_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float* dL, float* loss_accum) {
+    if (!rgb || !target || !dL) return DVS_ERR_INVALID;
+    if (count == 0) return DVS_OK;
+    hipLaunchKernelGGL(k_loss_grad<true>, dim3(grid_for(count)), dim3(TB), 0, (hipStream_t)stream, rgb, target, count,
+                       1.0f / (float)count, dL, loss_accum);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_l2_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float scale, float* dL, float* loss_accum) {
+    if (!rgb || !target || !dL) return DVS_ERR_INVALID;
+    if (count == 0) return DVS_OK;
+    hipLaunchKernelGGL(k_loss_grad<false>, dim3(grid_for(count)), dim3(TB), 0, (hipStream_t)stream, rgb, target, count, scale, dL,
+                       loss_accum);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_adam_step(void* stream, float* param, const float* grad, float* m, float* v, size_t count, float lr, float beta1,
+                  float beta2, float eps, int step) {
+    if (!param || !grad || !m || !v || step < 1) return DVS_ERR_INVALID;
+    if (count == 0) return DVS_OK;
+    const float bc1 = 1.0f / (1.0f - powf(beta1, (float)step)), bc2 = 1.0f / (1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(count)), dim3(TB), 0, (hipStream_t)stream, param, grad, m, v, count, lr, beta1, beta2,
+                       eps, bc1, bc2);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+}

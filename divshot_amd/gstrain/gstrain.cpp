@@ -1,0 +1,344 @@
+// gstrain.cpp — MI355X-native `libgstrain.so`: the plugin DIVSHOT's hosts dlopen (PluginManager::ensure_plugin_loaded
+// ("gstrain"), application/diverseshot-cli/source/gs_train.cpp:16-23 -> diverse/diverse_base/source/core/plugin.cpp:74,89)
+// and drive through nine C symbols (gs_train.cpp:24,105-109,144-150,178) plus the two every plugin exports
+// (plugin.cpp:89-111). The reference's implementation is closed source (README.md:46); this one keeps its call
+// sequence and ownership rules (scene allocated/freed by the plugin, config copied, bool from load_train_data) and
+// puts the MI355X rasterizer (include/dvs_raster.h) at the centre of train_step():
+//     sample camera -> dvs_raster_forward -> L1 loss gradient -> dvs_raster_backward -> fused Adam -> step++
+// Out of scope this round: SSIM term, densify/prune/opacity reset, COLMAP / image ingestion,
+// mesh export. load_train_data accepts a synthetic-scene spec instead of a dataset path.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdarg>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <map>
+#include <stdexcept>
+#include "../../include/gaussian_trainer_scene.hpp"
+#include "../../include/dvs_raster.h"
+#include "../../include/dvs_scene.h"
+#include "../../include/dvs_train.h"
+#include "ply_io.hpp"
+
+namespace {
+const int kWidth[6] = {3, 3, 45, 1, 3, 4};          // pos sh0 shN opacity scale rot
+enum { P_POS = 0, P_SH0, P_SHN, P_OPA, P_SCALE, P_ROT };
+
+void logf_(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void logf_(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    fputs("[gstrain] ", stderr); vfprintf(stderr, fmt, ap); fputc('\n', stderr);
+    va_end(ap);
+}
+#define HIP_OR_THROW(expr)                                                                          \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr ": ") + hipGetErrorString(e_)); } while (0)
+#define DVS_OR_THROW(expr)                                                                          \
+    do { int r_ = (expr); if (r_ != DVS_OK) throw std::runtime_error(std::string(#expr ": ") + dvs_last_error()); } while (0)
+
+struct Lcg {       // tiny deterministic noise source for the synthetic initialisation
+    uint64_t s;
+    explicit Lcg(uint64_t seed) : s(seed * 6364136223846793005ULL + 1442695040888963407ULL) {}
+    float uni() { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return (float)((s >> 40) * (1.0 / 16777216.0)); }
+    float sym() { return 2.f * uni() - 1.f; }
+};
+}  // namespace
+
+struct GaussianTrainerScene::Impl {
+    GaussianTrainConfig cfg;
+    int loadItr = -1;
+    TrainingStatus status = TrainingStatus::Loading_Prepare;
+    bool training = true;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    dvs_ctx* ctx = nullptr;
+    int n = 0, W = 0, H = 0, sh_max = 3;
+    float* d_param[6] = {}; float* d_grad[6] = {}; float* d_m[6] = {}; float* d_v[6] = {};
+    float* d_absgrad = nullptr;
+    std::vector<dvs_camera> cams;
+    std::vector<float*> d_targets;
+    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;
+    float last_loss = 0.f;
+    int step = 0;
+    uint64_t cam_rng = 88172645463325252ULL;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<float> host[6];
+    bool host_valid = false;
+
+    ~Impl() { release(); }
+    void release() {
+        if (device >= 0) (void)hipSetDevice(device);
+        for (int g = 0; g < 6; ++g) {
+            if (d_param[g]) (void)hipFree(d_param[g]);
+            if (d_grad[g]) (void)hipFree(d_grad[g]);
+            if (d_m[g]) (void)hipFree(d_m[g]);
+            if (d_v[g]) (void)hipFree(d_v[g]);
+            d_param[g] = d_grad[g] = d_m[g] = d_v[g] = nullptr;
+        }
+        for (float* t : d_targets) (void)hipFree(t);
+        d_targets.clear();
+        for (float** p : {&d_absgrad, &d_out, &d_dL, &d_loss}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (ctx) { dvs_destroy(ctx); ctx = nullptr; }
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    }
+    void alloc_params(int count, const std::vector<float> init[6]) {
+        n = count;
+        for (int g = 0; g < 6; ++g) {
+            const size_t bytes = (size_t)n * kWidth[g] * sizeof(float);
+            HIP_OR_THROW(hipMalloc((void**)&d_param[g], bytes ? bytes : 4));
+            HIP_OR_THROW(hipMalloc((void**)&d_grad[g], bytes ? bytes : 4));
+            HIP_OR_THROW(hipMalloc((void**)&d_m[g], bytes ? bytes : 4));
+            HIP_OR_THROW(hipMalloc((void**)&d_v[g], bytes ? bytes : 4));
+            HIP_OR_THROW(hipMemcpy(d_param[g], init[g].data(), bytes, hipMemcpyHostToDevice));
+            HIP_OR_THROW(hipMemset(d_m[g], 0, bytes));
+            HIP_OR_THROW(hipMemset(d_v[g], 0, bytes));
+        }
+        HIP_OR_THROW(hipMalloc((void**)&d_absgrad, (size_t)n * 2 * sizeof(float) + 4));
+    }
+    dvs_splats splats() const {
+        dvs_splats s{};
+        s.pos = d_param[P_POS]; s.sh0 = d_param[P_SH0]; s.shN = d_param[P_SHN]; s.opacity = d_param[P_OPA];
+        s.scale = d_param[P_SCALE]; s.rot = d_param[P_ROT]; s.n = n;
+        return s;
+    }
+    std::string model_file(int it) const { return cfg.modelPath + "_" + std::to_string(it) + ".ply"; }
+    void fetch_host() {
+        if (host_valid) return;
+        HIP_OR_THROW(hipStreamSynchronize(stream));
+        for (int g = 0; g < 6; ++g) {
+            host[g].resize((size_t)n * kWidth[g]);
+            HIP_OR_THROW(hipMemcpy(host[g].data(), d_param[g], host[g].size() * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        host_valid = true;
+    }
+    bool load_synthetic(const std::string& spec_str);
+};
+
+bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
+    // "synthetic:N=100000,W=800,H=800,cams=8,sh=3,seed=1"
+    std::map<std::string, double> kv = {{"N", 100000}, {"W", 800}, {"H", 800}, {"cams", 8}, {"sh", 3}, {"seed", 1}};
+    size_t p = spec_str.find(':');
+    std::string rest = p == std::string::npos ? "" : spec_str.substr(p + 1);
+    while (!rest.empty()) {
+        size_t c = rest.find(',');
+        std::string item = rest.substr(0, c);
+        rest = c == std::string::npos ? "" : rest.substr(c + 1);
+        size_t e = item.find('=');
+        if (e == std::string::npos) continue;
+        kv[item.substr(0, e)] = atof(item.substr(e + 1).c_str());
+    }
+    dvs_scene_spec spec{};
+    spec.n = (int)kv["N"]; spec.width = (int)kv["W"]; spec.height = (int)kv["H"]; spec.sh_degree = (int)kv["sh"];
+    spec.n_cams = (int)kv["cams"]; spec.seed = (uint64_t)kv["seed"]; spec.fov_x_deg = 60.f; spec.scale_log_offset = 0.f;
+    if (spec.n <= 0 || spec.width <= 0 || spec.height <= 0 || spec.n_cams <= 0 || spec.sh_degree < 0 || spec.sh_degree > 3) return false;
+    if (spec.width > cfg.maxImageWidth || spec.height > cfg.maxImageHeight)
+        logf_("note: synthetic image %dx%d exceeds maxImageWidth/Height %dx%d (kept as is)", spec.width, spec.height, cfg.maxImageWidth, cfg.maxImageHeight);
+    W = spec.width; H = spec.height; sh_max = spec.sh_degree;
+    std::vector<float> gt[6];
+    for (int g = 0; g < 6; ++g) gt[g].resize((size_t)spec.n * kWidth[g]);
+    DVS_OR_THROW(dvs_synth_splats(&spec, gt[0].data(), gt[1].data(), gt[2].data(), gt[3].data(), gt[4].data(), gt[5].data()));
+    ctx = dvs_create(device, (size_t)std::max(spec.n, cfg.capMax > 0 ? std::min(cfg.capMax, spec.n * 2) : spec.n), W, H);
+    if (!ctx) throw std::runtime_error(std::string("dvs_create: ") + dvs_last_error());
+    // ground-truth views: render the generating scene once per camera
+    alloc_params(spec.n, gt);
+    const size_t img = 3 * (size_t)W * H;
+    HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_loss, sizeof(float)));
+    dvs_opts opts{sh_max, cfg.mipAntiliased ? 1 : 0, 0, 0};
+    const dvs_splats sp = splats();
+    for (int c = 0; c < spec.n_cams; ++c) {
+        dvs_camera cam;
+        DVS_OR_THROW(dvs_synth_camera(&spec, c, &cam));
+        float* t = nullptr;
+        HIP_OR_THROW(hipMalloc((void**)&t, img * sizeof(float)));
+        DVS_OR_THROW(dvs_raster_forward(ctx, stream, &sp, &cam, &opts, t, nullptr, nullptr));
+        cams.push_back(cam); d_targets.push_back(t);
+    }
+    HIP_OR_THROW(hipStreamSynchronize(stream));
+    // trainable initialisation = perturbed ground truth (or the checkpoint when --load_itr is given)
+    std::vector<float> init[6];
+    bool resumed = false;
+    if (loadItr >= 0) {
+        std::string err;
+        resumed = gsply::read_ply(model_file(loadItr), init[0], init[1], init[2], init[3], init[4], init[5], &err) &&
+                  (int)init[3].size() == spec.n;
+        if (!resumed) logf_("could not resume from %s (%s): starting from the synthetic initialisation", model_file(loadItr).c_str(), err.c_str());
+        else step = loadItr;
+    }
+    if (!resumed) {
+        Lcg r(spec.seed + 17);
+        for (int g = 0; g < 6; ++g) init[g] = gt[g];
+        for (int i = 0; i < spec.n; ++i) {
+            const float z = gt[0][3 * i + 2];
+            for (int k = 0; k < 3; ++k) init[P_POS][3 * i + k] += 0.002f * z * r.sym();
+            for (int k = 0; k < 3; ++k) init[P_SH0][3 * i + k] += 0.5f * r.sym();
+            for (int k = 0; k < 45; ++k) init[P_SHN][45 * (size_t)i + k] = 0.f;
+            init[P_OPA][i] -= 1.0f;
+            for (int k = 0; k < 3; ++k) init[P_SCALE][3 * i + k] += 0.15f * r.sym();
+        }
+    }
+    for (int g = 0; g < 6; ++g)
+        HIP_OR_THROW(hipMemcpy(d_param[g], init[g].data(), init[g].size() * sizeof(float), hipMemcpyHostToDevice));
+    if (cfg.verbose) logf_("synthetic scene: %d splats, %d cameras @ %dx%d, SH degree %d%s", spec.n, spec.n_cams, W, H, sh_max, resumed ? " (resumed)" : "");
+    return true;
+}
+
+GaussianTrainerScene::GaussianTrainerScene(const GaussianTrainConfig& cfg, int loadItr) : impl_(new Impl()) {
+    impl_->cfg = cfg;
+    impl_->loadItr = loadItr;
+    const char* lr = getenv("LOCAL_RANK");
+    impl_->device = lr ? atoi(lr) : 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw std::runtime_error("gstrain: no HIP device visible (this plugin has no CPU fallback)");
+    impl_->device %= count;
+    HIP_OR_THROW(hipSetDevice(impl_->device));
+    HIP_OR_THROW(hipStreamCreate(&impl_->stream));
+}
+GaussianTrainerScene::~GaussianTrainerScene() = default;
+
+bool GaussianTrainerScene::loadTrainData(const std::string& path) {
+    Impl& m = *impl_;
+    try {
+        HIP_OR_THROW(hipSetDevice(m.device));
+        if (path.rfind("synthetic", 0) == 0) {
+            if (!m.load_synthetic(path)) { m.status = TrainingStatus::Loading_Failed; return false; }
+            m.status = TrainingStatus::Preprocess_Done;
+            trainSetup();
+            return true;
+        }
+        logf_("load_train_data('%s'): dataset ingestion (COLMAP / images) is outside this build's scope; use a 'synthetic:N=..,W=..,H=..,cams=..,sh=..,seed=..' spec", path.c_str());
+    } catch (const std::exception& e) {
+        logf_("load_train_data failed: %s", e.what());
+    }
+    m.status = TrainingStatus::Loading_Failed;
+    return false;
+}
+
+void GaussianTrainerScene::trainSetup() {
+    impl_->t0 = std::chrono::steady_clock::now();
+    impl_->status = TrainingStatus::Training;
+    curIteration = impl_->step;
+}
+
+void GaussianTrainerScene::trainStep() {
+    Impl& m = *impl_;
+    if (!m.ctx || m.cams.empty()) throw std::runtime_error("trainStep before loadTrainData");
+    HIP_OR_THROW(hipSetDevice(m.device));
+    // camera: xorshift over the view list (one view per iteration, as the reference's trainStep renders one camera)
+    m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
+    const int ci = (int)(m.cam_rng % m.cams.size());
+    const int it = m.step + 1;
+    const int deg = m.cfg.progressiveTrain ? std::min(m.sh_max, m.step / 1000) : m.sh_max;   // SH bands unlocked every 1000 steps
+    dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0};
+    const dvs_splats sp = m.splats();
+    DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, nullptr, nullptr));
+    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, sizeof(float), m.stream));
+    DVS_OR_THROW(dvs_l1_loss_grad(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, m.d_dL, m.d_loss));
+    dvs_splat_grads g{};
+    g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
+    g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = m.cfg.useAbsGrad ? m.d_absgrad : nullptr; g.mean2d = nullptr;
+    DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
+    // Adam, per-group learning rates (names gs_train.cpp:52-57; position lr decays exponentially init -> final)
+    const float t = std::min(1.0f, (float)m.step / (float)std::max(1, m.cfg.numIters));
+    const float lr_pos = std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
+    const float lr[6] = {lr_pos, m.cfg.featurelr, m.cfg.featurelr / 20.f, m.cfg.opacitylr, m.cfg.scalinglr, m.cfg.rotationlr};
+    for (int k = 0; k < 6; ++k)
+        DVS_OR_THROW(dvs_adam_step(m.stream, m.d_param[k], m.d_grad[k], m.d_m[k], m.d_v[k], (size_t)m.n * kWidth[k], lr[k], 0.9f, 0.999f,
+                                   1e-15f, it));
+    if (m.cfg.verbose && (m.step % 100 == 0))          // same line the editor logs (application/editor/source/editor.cpp:1554)
+        logf_("Iteraions %d, loss : %f", m.step, (double)getCurrentLoss());
+    m.step = it;
+    curIteration = it;
+    m.host_valid = false;
+    if (m.step >= m.cfg.numIters) m.status = TrainingStatus::Training_Done;
+}
+
+void GaussianTrainerScene::saveGaussianModel() {
+    Impl& m = *impl_;
+    m.fetch_host();
+    const std::string file = m.model_file(m.step);
+    std::error_code ec;
+    const auto parent = std::filesystem::path(file).parent_path();
+    if (!parent.empty()) std::filesystem::create_directories(parent, ec);
+    std::string err;
+    if (!gsply::write_ply(file, (size_t)m.n, m.host[0].data(), m.host[1].data(), m.host[2].data(), m.host[3].data(), m.host[4].data(),
+                          m.host[5].data(), m.cfg.mipAntiliased, &err))
+        logf_("save_splat_model: %s", err.c_str());
+    else if (m.cfg.verbose) logf_("saved %d splats to %s", m.n, file.c_str());
+}
+void GaussianTrainerScene::exportMesh(const std::string&) { logf_("export_mesh: mesh extraction is outside this build's scope"); }
+bool GaussianTrainerScene::isTrain() const { return impl_->training; }
+void GaussianTrainerScene::startTrain() { impl_->training = true; }
+void GaussianTrainerScene::pauseTrain() { impl_->training = false; }
+int GaussianTrainerScene::getCurrentIterations() const { return impl_->step; }
+float GaussianTrainerScene::getCurrentLoss() {
+    Impl& m = *impl_;
+    if (m.d_loss && m.stream) {
+        (void)hipStreamSynchronize(m.stream);
+        (void)hipMemcpy(&m.last_loss, m.d_loss, sizeof(float), hipMemcpyDeviceToHost);
+    }
+    return m.last_loss;
+}
+int& GaussianTrainerScene::maxIteriaons() { return impl_->cfg.numIters; }
+GaussianTrainConfig& GaussianTrainerScene::getTrainConfig() { return impl_->cfg; }
+GaussianTrainerScene::TrainingStatus GaussianTrainerScene::getCurrentTrainingStatus() const { return impl_->status; }
+void GaussianTrainerScene::setTrainingStatus(TrainingStatus s) { impl_->status = s; }
+double GaussianTrainerScene::getTrainingElpasedTime() const {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - impl_->t0).count();
+}
+int GaussianTrainerScene::getNumGaussians() const { return impl_->n; }
+int GaussianTrainerScene::getNumCameras() const { return (int)impl_->cams.size(); }
+const std::vector<float>& GaussianTrainerScene::getGaussianPositionCpu() { impl_->fetch_host(); return impl_->host[P_POS]; }
+const std::vector<float>& GaussianTrainerScene::getGaussianSH0Cpu() { impl_->fetch_host(); return impl_->host[P_SH0]; }
+const std::vector<float>& GaussianTrainerScene::getGaussianSHNCpu() { impl_->fetch_host(); return impl_->host[P_SHN]; }
+const std::vector<float>& GaussianTrainerScene::getGaussianOpcaitiesCpu() { impl_->fetch_host(); return impl_->host[P_OPA]; }
+const std::vector<float>& GaussianTrainerScene::getGaussianScalingsCpu() { impl_->fetch_host(); return impl_->host[P_SCALE]; }
+const std::vector<float>& GaussianTrainerScene::getGaussianRotationsCpu() { impl_->fetch_host(); return impl_->host[P_ROT]; }
+
+// ---- C symbols -------------------------------------------------------------------------------------------
+extern "C" {
+__attribute__((visibility("default"))) void gstrain_init() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) logf_("gstrain_init: no HIP device visible");
+    else logf_("gstrain_init: %d MI355X-class device(s), rasterizer '%s'", count, dvs_version());
+}
+__attribute__((visibility("default"))) void* create_splat(const GaussianTrainConfig& config, int loadItr) {
+    try { return new GaussianTrainerScene(config, loadItr); }
+    catch (const std::exception& e) { logf_("create_splat: %s", e.what()); return nullptr; }
+}
+__attribute__((visibility("default"))) bool load_train_data(GaussianTrainerScene* scene, const std::string& path) {
+    return scene && scene->loadTrainData(path);
+}
+__attribute__((visibility("default"))) void train_step(GaussianTrainerScene* scene) { if (scene) scene->trainStep(); }
+__attribute__((visibility("default"))) int get_cur_step(GaussianTrainerScene* scene) { return scene ? scene->getCurrentIterations() : 0; }
+__attribute__((visibility("default"))) void save_splat_model(GaussianTrainerScene* scene) { if (scene) scene->saveGaussianModel(); }
+__attribute__((visibility("default"))) void export_mesh(GaussianTrainerScene* scene) { if (scene) scene->exportMesh(""); }
+__attribute__((visibility("default"))) void delete_splat(GaussianTrainerScene* scene) { delete scene; }
+__attribute__((visibility("default"))) void gstrain_destroy() {}
+__attribute__((visibility("default"))) const char* get_description() { return "gstrain: MI355X-native Gaussian-splat trainer (divshot_amd)"; }
+__attribute__((visibility("default"))) void* create_instance() { return nullptr; }
+
+// plain-C helpers so the PLY wire format can be tested from Python without a GPU (tests/test_ply.py)
+__attribute__((visibility("default"))) int gstrain_write_ply(const char* path, uint64_t n, const float* pos, const float* sh0,
+                                                              const float* shN, const float* opacity, const float* scale,
+                                                              const float* rot, int antialiased) {
+    std::string err;
+    return gsply::write_ply(path, (size_t)n, pos, sh0, shN, opacity, scale, rot, antialiased != 0, &err) ? 0 : 1;
+}
+__attribute__((visibility("default"))) int64_t gstrain_read_ply(const char* path, float* pos, float* sh0, float* shN, float* opacity,
+                                                                float* scale, float* rot, uint64_t capacity) {
+    std::vector<float> a, b, c, d, e, f;
+    std::string err;
+    if (!gsply::read_ply(path, a, b, c, d, e, f, &err)) return -1;
+    const uint64_t n = d.size();
+    if (pos && n <= capacity) {
+        memcpy(pos, a.data(), a.size() * 4); memcpy(sh0, b.data(), b.size() * 4); memcpy(shN, c.data(), c.size() * 4);
+        memcpy(opacity, d.data(), d.size() * 4); memcpy(scale, e.data(), e.size() * 4); memcpy(rot, f.data(), f.size() * 4);
+    }
+    return (int64_t)n;
+}
+}

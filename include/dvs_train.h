@@ -1,0 +1,31 @@
+/*
+ * dvs_train.h — C-ABI of the two streaming ops that sit immediately before / after the rasterizer in
+ * train_step(): image loss + its gradient, and the fused Adam update of
+ * the 59-float splat rows. They exist so that libgstrain's train_step() is a real training iteration;
+ * the reference's own implementations live in the closed `gstrain` plugin (README.md:46). Flags that
+ * select them in the reference: --ssim (application/diverseshot-cli/source/main.cpp:24-25), learning
+ * rates (main.cpp:31, gs_train.cpp:52-57).
+ */
+#ifndef DVS_TRAIN_H
+#define DVS_TRAIN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mean-L1 image loss over count floats: dL[i] = sign(rgb[i]-target[i]) / count; *loss_accum += sum|rgb-target| / count.
+ * rgb, target, dL, loss_accum are DEVICE pointers; loss_accum (1 float) must be zeroed by the caller. Asynchronous. */
+int dvs_l1_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float* dL, float* loss_accum);
+/* Mean-squared-error variant (the upstream gradient bench.py uses): dL = (rgb-target) * (2/count)... scaled by `scale`. */
+int dvs_l2_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float scale, float* dL, float* loss_accum);
+
+/* Fused Adam over one parameter array (count floats): m, v are the moment arrays (same size, DEVICE).
+ * step is 1-based. Asynchronous. */
+int dvs_adam_step(void* stream, float* param, const float* grad, float* m, float* v, size_t count, float lr, float beta1,
+                  float beta2, float eps, int step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""B1 — the `gstrain` plugin boundary: exported symbols, PLY wire format (KAT-5), and — on the GPU —
+the full host call sequence of diverseshot-cli driving a short synthetic training run."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "divshot_amd", "lib")
+PLUGIN = os.path.join(LIB, "libgstrain.so")
+DRIVER = os.path.join(LIB, "gaussian_train")
+
+
+@pytest.fixture(scope="module")
+def plugin():
+    if not os.path.exists(PLUGIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "divshot_amd", "gstrain")])
+    return C.CDLL(PLUGIN)
+
+
+def test_plugin_exports_the_host_symbols(plugin):
+    # gs_train.cpp:24,105-109,144-150,178 + plugin.cpp:89-111
+    for name in ("gstrain_init", "create_splat", "load_train_data", "train_step", "get_cur_step", "save_splat_model",
+                 "export_mesh", "delete_splat", "gstrain_destroy", "get_description", "create_instance"):
+        assert hasattr(plugin, name), name
+    plugin.get_description.restype = C.c_char_p
+    assert b"gstrain" in plugin.get_description()
+
+
+def test_kat5_ply_wire_format(plugin, tmp_path):
+    """external/tinygsplat/tiny_gsplat.cpp:194-216 property order, 59 floats = 236 B per vertex, f_rest channel-major on disk
+    ([c*15+j], tiny_gsplat.cpp:231-236) vs coefficient-major in memory ([j*3+c], gaussian_model.cpp:163-167)."""
+    n = 257
+    rng = np.random.default_rng(5)
+    A = {"pos": rng.normal(size=(n, 3)), "sh0": rng.normal(size=(n, 3)), "shN": rng.normal(size=(n, 15, 3)),
+         "opacity": rng.normal(size=(n,)), "scale": rng.normal(size=(n, 3)), "rot": rng.normal(size=(n, 4))}
+    A = {k: np.ascontiguousarray(v, np.float32) for k, v in A.items()}
+    path = str(tmp_path / "m.ply").encode()
+    order = ("pos", "sh0", "shN", "opacity", "scale", "rot")
+    plugin.gstrain_write_ply.argtypes = [C.c_char_p, C.c_uint64] + [C.c_void_p] * 6 + [C.c_int]
+    assert plugin.gstrain_write_ply(path, n, *[A[k].ctypes.data for k in order], 1) == 0
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().strip().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+    assert "comment splatx.anti_aliasing=1" in lines and f"element vertex {n}" in lines
+    props = [l.split()[-1] for l in lines if l.startswith("property float")]
+    want = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + ["opacity", "scale_0", "scale_1", "scale_2",
+                                                                                                 "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert props == want
+    assert len(body) == n * 236
+    row = np.frombuffer(body, np.float32).reshape(n, 59)
+    assert np.array_equal(row[:, 0:3], A["pos"]) and np.array_equal(row[:, 3:6], A["sh0"])
+    assert np.array_equal(row[:, 6:51].reshape(n, 3, 15), A["shN"].transpose(0, 2, 1))       # f_rest[c*15+j] = shN[j][c]
+    assert np.array_equal(row[:, 51], A["opacity"]) and np.array_equal(row[:, 52:55], A["scale"]) and np.array_equal(row[:, 55:59], A["rot"])
+    B = {k: np.zeros_like(v) for k, v in A.items()}
+    plugin.gstrain_read_ply.restype = C.c_int64
+    plugin.gstrain_read_ply.argtypes = [C.c_char_p] + [C.c_void_p] * 6 + [C.c_uint64]
+    assert plugin.gstrain_read_ply(path, *[B[k].ctypes.data for k in order], n) == n
+    for k in order:
+        assert np.array_equal(A[k], B[k]), k
+
+
+@pytest.mark.gpu
+def test_cli_trains_synthetic_scene(tmp_path):
+    """The host sequence init -> create -> load -> {get_cur_step, train_step}* -> save -> delete -> destroy, end to end."""
+    out = str(tmp_path / "model" / "iteration")
+    cmd = [DRIVER, "--inputPath", "synthetic:N=20000,W=256,H=256,cams=4,sh=1,seed=3", "--maxIteration", "400", "--outputPath", out]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    losses = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+)", p.stderr)]
+    assert len(losses) >= 4
+    assert losses[-1] < 0.7 * losses[0], losses
+    assert "Train Done" in p.stdout
+    ply = out + "_400.ply"
+    assert os.path.exists(ply) and os.path.getsize(ply) > 20000 * 236
+    # resume from the checkpoint (--load_itr, main.cpp:40-41)
+    cmd2 = cmd[:]
+    cmd2[cmd2.index("400")] = "450"
+    p2 = subprocess.run(cmd2 + ["--load_itr", "400"], capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0 and "(resumed)" in p2.stderr, p2.stderr
+    assert os.path.exists(out + "_450.ply")
+    # unknown flags are an error (CLI11 allow_config_extras(error), main.cpp:11); a dataset path is refused loudly
+    assert subprocess.run([DRIVER, "--bogus", "1"], capture_output=True).returncode != 0
+    p3 = subprocess.run([DRIVER, "--inputPath", "/nonexistent/dataset"], capture_output=True, text=True)
+    assert p3.returncode != 0 and "load data failed" in p3.stdout
