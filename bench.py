@@ -87,7 +87,8 @@ def main():
     import numpy as np
     import torch
     import divshot_amd as dv
-    from divshot_amd.raster import Rasterizer, params_to_device, PARAM_KEYS, PARAM_WIDTH
+    from divshot_amd.raster import Rasterizer, params_to_device
+    from divshot_amd.parallel import GradBuffer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -113,12 +114,8 @@ def main():
     params = params_to_device(P, dev)
     rast = Rasterizer(local_rank, max_splats=n, max_w=W, max_h=H)
     # one flat gradient buffer so the exchange is a single large collective (236 B/splat)
-    flat = torch.zeros(n * 59, dtype=torch.float32, device=dev)
-    grads, off = {}, 0
-    for k in PARAM_KEYS:
-        w = PARAM_WIDTH[k]
-        grads[k] = flat[off:off + n * w].view(params[k].shape)
-        off += n * w
+    gbuf = GradBuffer(n, dev)
+    flat, grads = gbuf.flat, dict(gbuf.views)
     if args.absgrad:
         grads["absgrad2d"] = torch.zeros((n, 2), dtype=torch.float32, device=dev)
     out = torch.empty((3, H, W), dtype=torch.float32, device=dev)

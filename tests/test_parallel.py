@@ -1,0 +1,66 @@
+"""N>1 path on CPU: two gloo processes exercise the view sharding and the flat-buffer gradient all-reduce that bench.py
+runs over RCCL. The rasterizer itself needs a GPU; here each rank fills its rows with known values."""
+import os
+import socket
+import sys
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, out):
+    sys.path.insert(0, ROOT)
+    from divshot_amd.parallel import GradBuffer, views_for_rank, PARAM_KEYS
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gb = GradBuffer(n, torch.device("cpu"))
+    total = {k: torch.zeros_like(gb.views[k]) for k in PARAM_KEYS}
+    # every rank "renders" its shard of 8 views; view v contributes (v+1) * ramp to every group
+    for v in views_for_rank(8, rank, world):
+        for i, k in enumerate(PARAM_KEYS):
+            gb.views[k] += (v + 1) * (i + 1) * torch.arange(gb.views[k].numel(), dtype=torch.float32).view(gb.views[k].shape) * 1e-3
+    gb.all_reduce()
+    for i, k in enumerate(PARAM_KEYS):
+        want = sum(range(1, 9)) * (i + 1) * torch.arange(gb.views[k].numel(), dtype=torch.float32).view(gb.views[k].shape) * 1e-3
+        assert torch.allclose(gb.views[k], want, rtol=1e-6), k
+    out.put((rank, float(gb.flat.sum())))
+    dist.destroy_process_group()
+
+
+def test_view_sharding():
+    from divshot_amd.parallel import views_for_rank
+    for world in (1, 2, 4, 8):
+        seen = sorted(v for r in range(world) for v in views_for_rank(8, r, world))
+        assert seen == list(range(8))
+        assert all(len(views_for_rank(8, r, world)) == 8 // world for r in range(world))
+
+
+def test_grad_buffer_layout():
+    from divshot_amd.parallel import GradBuffer, ROW_FLOATS
+    gb = GradBuffer(10, torch.device("cpu"))
+    assert ROW_FLOATS == 59 and gb.flat.numel() == 590          # 59 fp32 = 236 B per splat (editor.cpp:1578)
+    gb.views["rot"][3, 2] = 7.0
+    assert gb.flat[10 * (3 + 3 + 45 + 1 + 3) + 3 * 4 + 2] == 7.0
+    assert gb.all_reduce() is None                              # no process group: single-GPU path is a no-op
+
+
+def test_two_rank_gradient_allreduce_gloo():
+    world, n = 2, 257
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sums = dict(out.get(timeout=5) for _ in range(world))
+    assert abs(sums[0] - sums[1]) < 1e-3 * abs(sums[0])         # replicas hold identical reduced gradients
