@@ -77,11 +77,11 @@ __device__ __forceinline__ void wave_reduce12(const float v[12], float q[3]) {
 }
 
 // ---- batch staging + per-quadrant culling masks -------------------------------------------------------
-// Lane t of the workgroup gathers splat t of the batch into LDS and tests the axis-aligned bounding box of
-// the region where the splat can reach alpha >= 1/255 ( x^T Q x <= 2 ln(255 o), Q = conic ) against the four
-// 8x8 quadrants of the tile. One ballot per quadrant turns the tests into 64-bit wave masks: the wave that
+// Lane t of the workgroup gathers splat t of the batch into LDS and tests the ellipse on which the splat reaches
+// alpha = 1/255 ( d^T Q d = 2 ln(255 o), Q = conic ) against the four 8x8 quadrants of the tile (exact
+// ellipse-rectangle test). One ballot per quadrant turns the tests into 64-bit wave masks: the wave that
 // owns quadrant q later walks only the set bits (s_ff1 / s_flbit, scalar unit) and never spends a vector
-// instruction on a splat that cannot touch its pixels. The box is inflated (1e-4 rel + 0.01 px) so the
+// instruction on a splat that cannot touch its pixels. The bound is inflated (1e-4 rel + 1e-3) so the
 // exact per-pixel alpha test — unchanged — decides every contribution: results are identical to a full walk.
 struct __attribute__((aligned(16))) BatchLds {
     float4 co[RB];
@@ -104,16 +104,23 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         L.xy[t] = xy;
         L.co[t] = co;
         L.rgb[t] = make_float4(rgb[3 * (size_t)id], rgb[3 * (size_t)id + 1], rgb[3 * (size_t)id + 2], 0.f);
-        const float tau2 = 2.0f * __logf(255.0f * co.w);
-        const float k = tau2 / (co.x * co.z - co.y * co.y);
-        const float hx = sqrtf(co.z * k) * 1.0001f + 0.01f;
-        const float hy = sqrtf(co.x * k) * 1.0001f + 0.01f;
-        const float lx = xy.x - hx - tile_x0, ux = xy.x + hx - tile_x0;     // box relative to the tile origin
-        const float ly = xy.y - hy - tile_y0, uy = xy.y + hy - tile_y0;
+        // The splat can reach alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o), d = pixel - mean.
+        // Minimise the convex form q over each quadrant's pixel rectangle (exact: origin inside -> 0, otherwise the
+        // minimum lies on one of the four edges) and keep the splat for that quadrant iff the minimum is within the bound.
+        const float bound = 2.0f * __logf(255.0f * co.w) * 1.0001f + 1e-3f;
+        const float a = co.x, b = co.y, c = co.z;
+        const float nb_c = -b / c, nb_a = -b / a;
+        const float ox = tile_x0 - xy.x, oy = tile_y0 - xy.y;                 // tile origin relative to the mean
+        auto qmin = [&](float x0, float x1, float y0, float y1) -> float {
+            if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
+            auto qf = [&](float x, float y) { return a * x * x + 2.f * b * x * y + c * y * y; };
+            const float e0 = qf(x0, fminf(fmaxf(nb_c * x0, y0), y1)), e1 = qf(x1, fminf(fmaxf(nb_c * x1, y0), y1));
+            const float e2 = qf(fminf(fmaxf(nb_a * y0, x0), x1), y0), e3 = qf(fminf(fmaxf(nb_a * y1, x0), x1), y1);
+            return fminf(fminf(e0, e1), fminf(e2, e3));
+        };
         // NaN-safe: a failed comparison keeps the splat
-        const bool x_lo = !(ux < 0.f) && !(lx > 7.f), x_hi = !(ux < 8.f) && !(lx > 15.f);
-        const bool y_lo = !(uy < 0.f) && !(ly > 7.f), y_hi = !(uy < 8.f) && !(ly > 15.f);
-        qm = (x_lo && y_lo ? 1u : 0u) | (x_hi && y_lo ? 2u : 0u) | (x_lo && y_hi ? 4u : 0u) | (x_hi && y_hi ? 8u : 0u);
+        qm = (!(qmin(ox, ox + 7.f, oy, oy + 7.f) > bound) ? 1u : 0u) | (!(qmin(ox + 8.f, ox + 15.f, oy, oy + 7.f) > bound) ? 2u : 0u) |
+             (!(qmin(ox, ox + 7.f, oy + 8.f, oy + 15.f) > bound) ? 4u : 0u) | (!(qmin(ox + 8.f, ox + 15.f, oy + 8.f, oy + 15.f) > bound) ? 8u : 0u);
     }
     const uint64_t m0 = __ballot(qm & 1u), m1 = __ballot(qm & 2u), m2 = __ballot(qm & 4u), m3 = __ballot(qm & 8u);
     if ((t & 63) == 0) {
@@ -154,28 +161,31 @@ k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
         stage_batch(L, sorted_splat, range.x + base, cnt, mean2d, conic_opacity, rgb, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
         __syncthreads();
         if (__all(done)) continue;               // this wave's quadrant is finished
+        // Predicated body (no per-lane branches: the scalar unit is shared by the CU's four SIMDs and a branchy
+        // body made this kernel scalar-bound); the wave-uniform "everyone finished" exit is checked per 64-splat word.
 #pragma unroll 1
         for (int lw = 0; lw < RB / 64; ++lw) {
             uint64_t m = uniform_u64(L.qmask[lw][wave]);
+            if (m == 0) continue;
+            if (__all(done)) break;
             while (m) {
-                if (__all(done)) { lw = RB / 64; break; }
                 const int j = lw * 64 + __builtin_ctzll(m);
                 m &= m - 1;
-                if (done) continue;
                 const float2 xy = L.xy[j];
                 const float4 co = L.co[j];
+                const float4 c = L.rgb[j];
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power > 0.f) continue;
                 const float alpha = fminf(DVS_ALPHA_MAX, co.w * __expf(power));
-                if (alpha < DVS_ALPHA_MIN) continue;
+                const bool valid = !done && !(power > 0.f) && !(alpha < DVS_ALPHA_MIN);
                 const float test_T = T * (1.f - alpha);
-                if (test_T < DVS_T_STOP) { done = true; continue; }
-                const float4 c = L.rgb[j];
-                const float w = alpha * T;
+                const bool stop = valid && (test_T < DVS_T_STOP);
+                const bool take = valid && !stop;
+                done = done || stop;
+                const float w = take ? alpha * T : 0.f;
                 C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
-                T = test_T;
-                last = (uint32_t)(base + j + 1);
+                T = take ? test_T : T;
+                last = take ? (uint32_t)(base + j + 1) : last;
             }
         }
     }
