@@ -242,9 +242,11 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
     for (int w = 0; w < RB / 64; ++w) todo = max(todo, s_max[w]);
     if (todo == 0) return;
 
+    // Back-to-front state per pixel: T = transmittance in front of the current splat, and ONE scalar
+    // D = sum over the splats behind of (c_k . dL/dC) alpha_k T_k + T_final (bg . dL/dC): because the upstream pixel
+    // gradient is constant along the list, dL/dalpha_j = (c_j . dL/dC) T_j - D / (1 - alpha_j) needs no per-channel state.
     float T = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-
+    float D = T_final * bg_dot;
     const int nbatch = (int)((todo + RB - 1) / RB);
     for (int b = nbatch - 1; b >= 0; --b) {
         const int base = b * RB;
@@ -272,36 +274,28 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 const float alpha = fminf(DVS_ALPHA_MAX, oa);
                 const bool contrib = (k < last) && !(power > 0.f) && !(alpha < DVS_ALPHA_MIN);
                 if (!__any(contrib)) continue;
+                // predicated: a non-contributing lane runs with alpha = 0 (T, D unchanged, every partial exactly 0)
+                const float4 c = L.rgb[j];
+                const float al = contrib ? alpha : 0.f;
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);        // 1-alpha >= 0.01: v_rcp_f32 (1 ulp) is ample
+                T = T * inv_1ma;
+                const float w = al * T;
+                const float cd = (c.x * dLp0 + c.y * dLp1) + c.z * dLp2;
+                float dL_dalpha = cd * T - D * inv_1ma;
+                D = D + cd * w;
+                dL_dalpha = (contrib && !(oa > DVS_ALPHA_MAX)) ? dL_dalpha : 0.f;   // the 0.99 clamp blocks the gradient
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float h = -0.5f * dL_dG;
                 float v[12];
-#pragma unroll
-                for (int e = 0; e < 12; ++e) v[e] = 0.f;
-                if (contrib) {
-                    const float4 c = L.rgb[j];
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);     // 1-alpha >= 0.01: v_rcp_f32 (1 ulp) is ample
-                    T = T * inv_1ma;
-                    const float dchannel_dcolor = alpha * T;
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    lc0 = c.x; lc1 = c.y; lc2 = c.z;
-                    float dL_dalpha = ((c.x - acc0) * dLp0 + (c.y - acc1) * dLp1) + (c.z - acc2) * dLp2;
-                    v[6] = dchannel_dcolor * dLp0; v[7] = dchannel_dcolor * dLp1; v[8] = dchannel_dcolor * dLp2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha -= T_final * inv_1ma * bg_dot;
-                    if (!(oa > DVS_ALPHA_MAX)) {
-                        const float dL_dG = co.w * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                        const float dG_ddely = -gdy * co.z - gdx * co.y;
-                        v[0] = dL_dG * dG_ddelx; v[1] = dL_dG * dG_ddely;
-                        if (ABSGRAD) { v[9] = fabsf(v[0]); v[10] = fabsf(v[1]); }
-                        v[2] = -0.5f * gdx * dx * dL_dG;
-                        v[3] = -gdx * dy * dL_dG;
-                        v[4] = -0.5f * gdy * dy * dL_dG;
-                        v[5] = G * dL_dalpha;
-                    }
-                }
+                v[0] = dL_dG * (-gdx * co.x - gdy * co.y);
+                v[1] = dL_dG * (-gdy * co.z - gdx * co.y);
+                v[2] = gdx * dx * h;
+                v[3] = gdx * dy * (h + h);
+                v[4] = gdy * dy * h;
+                v[5] = G * dL_dalpha;
+                v[6] = w * dLp0; v[7] = w * dLp1; v[8] = w * dLp2;
+                v[9] = ABSGRAD ? fabsf(v[0]) : 0.f; v[10] = ABSGRAD ? fabsf(v[1]) : 0.f; v[11] = 0.f;
                 float q[3];
                 wave_reduce12(v, q);
                 if (publisher) {
