@@ -62,6 +62,7 @@ _PROTOS = {
     "dvs_sort_pairs_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "dvs_export_sorted_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "dvs_keep_bwd_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_get_stage_timing": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float))]),
     "dvs_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

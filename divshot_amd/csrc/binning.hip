@@ -17,8 +17,7 @@
 
 #define SORT_BLOCK 256
 #define SORT_WAVES (SORT_BLOCK / 64)
-#define SORT_ITEMS 8
-#define SORT_PART (SORT_BLOCK * SORT_ITEMS)   // keys per workgroup
+// keys per workgroup = SORT_BLOCK * ITEMS; ITEMS = 8 (small inputs: more workgroups) or 16 (large inputs: longer runs per digit)
 #define RADIX 256
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -55,13 +54,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 }
 
 // ---- A5: one LSD pass = histogram, row scan, scatter -----------------------------------------------
-// wave w of block b owns the contiguous items [b*PART + w*512, +512), read in 8 rounds of 64.
+// wave w of block b owns the contiguous items [b*PART + w*64*ITEMS, +64*ITEMS), read in ITEMS rounds of 64.
+template <int SORT_ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t dmask, uint32_t* __restrict__ hist, uint32_t num_blocks) {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX];
     for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr int SORT_PART = SORT_BLOCK * SORT_ITEMS;
     const uint64_t wbase = (uint64_t)blockIdx.x * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -99,16 +100,25 @@ k_sort_rowscan(uint32_t* __restrict__ hist, uint32_t num_blocks, uint32_t* __res
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// Scatter: rank the partition's 4096 keys (stable, wave64 multisplit), order them by digit in LDS, then write them out
+// slot by slot: consecutive lanes hold consecutive keys of the same digit, so the global stores are runs of full
+// cache lines instead of 64 scattered dwords per instruction.
+template <int SORT_ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
                uint32_t* __restrict__ vals_out, uint64_t n, int shift, uint32_t dmask, const uint32_t* __restrict__ hist,
                const uint32_t* __restrict__ totals, uint32_t num_blocks) {
-    __shared__ uint32_t cnt[SORT_WAVES][RADIX];     // per-wave digit counts, then per-wave destination bases
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX];     // per-wave digit counts, then per-wave local bases
+    __shared__ uint32_t gdelta[RADIX];              // global destination of LDS slot s with digit d = gdelta[d] + s
     __shared__ uint32_t tmp[SORT_WAVES + 1];
+    constexpr int SORT_PART = SORT_BLOCK * SORT_ITEMS;
+    __shared__ uint32_t stage_k[SORT_PART];
+    __shared__ uint32_t stage_v[SORT_PART];
     for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint64_t wbase = (uint64_t)blockIdx.x * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
+    const uint64_t pbase = (uint64_t)blockIdx.x * SORT_PART;
+    const uint64_t wbase = pbase + (uint64_t)wave * (64 * SORT_ITEMS);
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -133,43 +143,66 @@ k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict_
     }
     __syncthreads();
     {
-        // thread d: global base of digit d for this block, then per-wave bases
         const uint32_t d = threadIdx.x;
-        uint32_t tot;
-        const uint32_t digit_excl = block_excl_scan(totals[d], tmp, &tot);
-        uint32_t run = digit_excl + hist[(uint64_t)d * num_blocks + blockIdx.x];
+        uint32_t c[SORT_WAVES], bc = 0;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) { const uint32_t c = cnt[w][d]; cnt[w][d] = run; run += c; }
+        for (int w = 0; w < SORT_WAVES; ++w) { c[w] = cnt[w][d]; bc += c[w]; }
+        uint32_t tot;
+        const uint32_t loff = block_excl_scan(bc, tmp, &tot);                 // where digit d starts in the LDS stage
+        const uint32_t digit_excl = block_excl_scan(totals[d], tmp, &tot);    // where digit d starts globally
+        gdelta[d] = digit_excl + hist[(uint64_t)d * num_blocks + blockIdx.x] - loff;
+        uint32_t run = loff;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) { cnt[w][d] = run; run += c[w]; }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
         if (idx < n) {
-            const uint32_t d = (key[r] >> shift) & dmask;
-            const uint32_t dst = cnt[wave][d] + rank[r];
-            keys_out[dst] = key[r];
-            vals_out[dst] = val[r];
+            const uint32_t pos = cnt[wave][(key[r] >> shift) & dmask] + rank[r];
+            stage_k[pos] = key[r];
+            stage_v[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = (uint32_t)((n - pbase) < (uint64_t)SORT_PART ? (n - pbase) : (uint64_t)SORT_PART);
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const uint32_t slot = (uint32_t)i * SORT_BLOCK + threadIdx.x;
+        if (slot < nvalid) {
+            const uint32_t k = stage_k[slot];
+            const uint32_t dst = gdelta[(k >> shift) & dmask] + slot;
+            keys_out[dst] = k;
+            vals_out[dst] = stage_v[slot];
         }
     }
 }
 
+static inline int sort_items_for(uint64_t n) { return n <= 1500000ull ? 8 : 16; }
+
 size_t dvs_sort_scratch_words(uint64_t n) {
-    const uint64_t nb = (n + SORT_PART - 1) / SORT_PART;
+    const uint64_t nb = (n + SORT_BLOCK * 8 - 1) / (SORT_BLOCK * 8);      // sized for the smaller partition
     return (size_t)(nb * RADIX + RADIX);
 }
 
 hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                                 uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch) {
     if (n == 0) return hipSuccess;
-    const uint32_t nb = (uint32_t)((n + SORT_PART - 1) / SORT_PART);
+    const int items = sort_items_for(n);
+    const uint32_t nb = (uint32_t)((n + (uint64_t)SORT_BLOCK * items - 1) / ((uint64_t)SORT_BLOCK * items));
     uint32_t* hist = scratch;
     uint32_t* totals = scratch + (size_t)nb * RADIX;
     const uint32_t dmask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
-    hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, dmask, hist, nb);
+    if (items == 8) hipLaunchKernelGGL(k_sort_hist<8>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, dmask, hist, nb);
+    else hipLaunchKernelGGL(k_sort_hist<16>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, dmask, hist, nb);
     hipLaunchKernelGGL(k_sort_rowscan, dim3(RADIX), dim3(SORT_BLOCK), 0, st, hist, nb, totals);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
-                       dmask, hist, totals, nb);
+    if (items == 8)
+        hipLaunchKernelGGL(k_sort_scatter<8>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+                           dmask, hist, totals, nb);
+    else
+        hipLaunchKernelGGL(k_sort_scatter<16>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+                           dmask, hist, totals, nb);
     return hipGetLastError();
 }
 

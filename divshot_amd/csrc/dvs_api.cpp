@@ -73,6 +73,8 @@ struct dvs_ctx {
     uint64_t* total_host = nullptr;      // pinned
     dvs_fwd_state st{};
     bool have_fwd = false;
+    bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
+    bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     // stage timing
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -279,7 +281,8 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     timing_reset(c);
     StageTimer tm(c, st);
     size_t e0 = tm.mark();
-    HIPCHECK(hipMemsetAsync(c->g_rows.p, 0, (size_t)n * 48, st));
+    if (!c->rows_clean) HIPCHECK(hipMemsetAsync(c->g_rows.p, 0, c->g_rows.bytes, st));
+    c->rows_clean = false;
     size_t e1 = tm.mark(); tm.span("bwd_zero", e0, e1);
     HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.mean2d, s.conic_opacity,
                                    s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
@@ -290,7 +293,8 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
                                        s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
                                        out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d,
-                                       opts->accumulate));
+                                       opts->accumulate, c->keep_rows ? 0 : 1));
+    c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
     size_t e3 = tm.mark(); tm.span("preprocess_bwd", e2, e3);
     if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, true); }
     return DVS_OK;
@@ -326,6 +330,8 @@ int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
     HIPCHECK(dvs_launch_export_keys((hipStream_t)stream, c->st.num_rendered, c->st.sorted_tile, c->st.sorted_splat, c->st.depth, out_keys));
     return DVS_OK;
 }
+
+int dvs_keep_bwd_intermediates(dvs_ctx* c, int keep) { if (!c) return DVS_ERR_INVALID; c->keep_rows = keep != 0; return DVS_OK; }
 
 int dvs_get_bwd_intermediates(dvs_ctx* c, const float** rows, int* row_floats) {
     if (!c) return DVS_ERR_INVALID;

@@ -12,10 +12,10 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
-                                     const int* radii, const uint32_t* flags, const float* grad_rows /*[n,12]*/,
+                                     const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
                                      float* g_pos, float* g_sh0, float* g_shN, float* g_opacity, float* g_scale,
                                      float* g_rot, float* out_absgrad2d /*nullable*/, float* out_mean2d /*nullable*/,
-                                     int accumulate);
+                                     int accumulate, int rezero_rows);
 
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort_pass needs for n items.

@@ -51,6 +51,9 @@ class Rasterizer:
             assert t.numel() == n * PARAM_WIDTH[k], k
         return Splats(*[params[k].data_ptr() for k in PARAM_KEYS], n, 0)
 
+    def keep_intermediates(self, on=True):
+        check(lib.dvs_keep_bwd_intermediates(self.ctx, 1 if on else 0))
+
     def enable_timing(self, on=True):
         check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))
 

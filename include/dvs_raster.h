@@ -150,6 +150,9 @@ int dvs_export_sorted_keys(dvs_ctx* ctx, void* stream, uint64_t* out_keys);
 /* Intermediate gradients of the last backward (A8 output; DEVICE, ctx-owned): one row of *row_floats (=12) fp32 per
  * splat: dL/dmean2D x,y | dL/dconic a,b,c | dL/dopacity | dL/drgb r,g,b | sum|dL/dmean2D| x,y | pad — for stage-level parity. */
 int dvs_get_bwd_intermediates(dvs_ctx* ctx, const float** rows, int* row_floats);
+/* By default the backward re-zeroes each row as A9 consumes it (no separate memset pass per view); keep = 1 leaves the rows
+ * in place so dvs_get_bwd_intermediates() can be read after dvs_raster_backward (parity tests). */
+int dvs_keep_bwd_intermediates(dvs_ctx* ctx, int keep);
 
 /* Per-stage GPU time (ms) of the last forward/backward, measured with hipEvents on the caller's stream
  * when profiling is enabled. names/ms arrays are ctx-owned; returns the number of stages. */

@@ -28,6 +28,7 @@ CONFIGS = {
 def rast(gpu_device):
     from divshot_amd.raster import Rasterizer
     r = Rasterizer(0, max_splats=1 << 20, max_w=1920, max_h=1080)
+    r.keep_intermediates(True)          # stage-level parity of A8 reads the gradient rows after the backward
     yield r
     r.close()
 

@@ -12,7 +12,7 @@ n, W, H, deg = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (10000,
 aa = len(sys.argv) > 5 and sys.argv[5] == "aa"
 seed = int(os.environ.get("SEED", "1")); soff = float(os.environ.get("SOFF", "0"))
 spec, P, cam, tgt = scene(n, W, H, deg, seed, scale_offset=soff)
-r = Rasterizer(0, max_splats=max(n, 1), max_w=W, max_h=H)
+r = Rasterizer(0, max_splats=max(n, 1), max_w=W, max_h=H); r.keep_intermediates(True)
 Pd = params_to_device(P, r.tdev)
 img = r.forward(Pd, cam, sh_degree=deg, antialias=aa, absgrad=True)
 torch.cuda.synchronize()
