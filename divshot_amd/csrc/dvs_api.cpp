@@ -6,7 +6,7 @@
 // application/editor/source/editor.cpp:1620).
 //
 // HBM layout (all arenas are ctx-owned, grow-only, sized for max_splats / max image at create):
-//   per splat   : radii i32 | mean2d f32x2 | depth f32 | conic_opacity f32x4 | rgb f32x3 | flags u32 |
+//   per splat   : radii i32 | mean2d f32x2 | depth f32 | conic_opacity f32x4 | rgb f32x4 (r,g,b,0) | flags u32 |
 //                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 64 B/splat
 //   per instance: tile u32 x2 | splat u32 x2 (ping-pong)                                              = 16 B/instance
 //   per tile    : range u32x2          per pixel: final_T f32, n_contrib u32
@@ -112,7 +112,7 @@ void timing_collect(dvs_ctx* c, bool append) {
 int ensure_splat_arenas(dvs_ctx* c, size_t n) {
     int r;
 #define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
-    ENS(radii, n * 4) ENS(mean2d, n * 8) ENS(depth, n * 4) ENS(conic_opacity, n * 16) ENS(rgb, n * 12)
+    ENS(radii, n * 4) ENS(mean2d, n * 8) ENS(depth, n * 4) ENS(conic_opacity, n * 16) ENS(rgb, n * 16)
     ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
     ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
     ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)

@@ -63,11 +63,18 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
                  const float* __restrict__ opacity, const float* __restrict__ scale, const float* __restrict__ rot,
                  DvsCam cam, int deg, int antialias, int tiles_x, int tiles_y,
                  int* __restrict__ radii, float2* __restrict__ mean2d, float* __restrict__ depth,
-                 float4* __restrict__ conic_opacity, float* __restrict__ rgb, uint32_t* __restrict__ flags,
+                 float4* __restrict__ conic_opacity, float4* __restrict__ rgb /*[n] r,g,b,0*/, uint32_t* __restrict__ flags,
                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] when deg>0
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
+    // issue this lane's own parameter loads first so they are in flight together with the cooperative shN staging
+    const int il = i < n ? i : (n - 1);
+    const float in_px = pos[3 * (int64_t)il], in_py = pos[3 * (int64_t)il + 1], in_pz = pos[3 * (int64_t)il + 2];
+    const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
+    const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
+    const float in_op = opacity[il];
+    const float in_dc0 = sh0[3 * (int64_t)il], in_dc1 = sh0[3 * (int64_t)il + 1], in_dc2 = sh0[3 * (int64_t)il + 2];
     if (deg > 0) {
         stage_rows_in<45>(shN, lds, base, n);
         __syncthreads();
@@ -82,7 +89,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
     float out_rgb[3] = {0.f, 0.f, 0.f};
 
     do {
-        const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
+        const float px = in_px, py = in_py, pz = in_pz;
         const float tx = dvs_xform(cam.view, px, py, pz, 0);
         const float ty = dvs_xform(cam.view, px, py, pz, 1);
         const float tz = dvs_xform(cam.view, px, py, pz, 2);
@@ -93,10 +100,8 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float pw = 1.0f / (hw + 0.0000001f);
         const float ndc_x = hx * pw, ndc_y = hy * pw;
 
-        float s[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] = dvs_exp_det(scale[3 * (int64_t)i + k]);
-        const float4 q4 = reinterpret_cast<const float4*>(rot)[i];
+        const float s[3] = {dvs_exp_det(in_s0), dvs_exp_det(in_s1), dvs_exp_det(in_s2)};
+        const float4 q4 = in_q;
         const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
         const float qn = dvs_sqrt_rn(((qr * qr + qx * qx) + qy * qy) + qz * qz);
         if (!(qn > 0.f)) break;
@@ -135,7 +140,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float a = cxx + DVS_LOWPASS, b = cxy, c = cyy + DVS_LOWPASS;
         const float det = a * c - b * b;
         if (!(det > 0.f)) break;
-        float opac = dvs_sigmoid_det(opacity[i]);
+        float opac = dvs_sigmoid_det(in_op);
         if (antialias) {
             const float det_orig = cxx * cyy - b * b;
             const float aa = dvs_sqrt_rn(fmaxf(0.f, det_orig / det));
@@ -163,9 +168,10 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         dvs_sh_basis(deg, dx * inv_dl, dy * inv_dl, dz * inv_dl, bas);
         const int ncoef = (deg + 1) * (deg + 1);
         const float* row = lds + threadIdx.x * 45;
+        const float in_dc[3] = {in_dc0, in_dc1, in_dc2};
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float col = bas[0] * sh0[3 * (int64_t)i + ch];
+            float col = bas[0] * in_dc[ch];
             for (int k = 1; k < ncoef; ++k) col = col + bas[k] * row[(k - 1) * 3 + ch];
             col = col + 0.5f;
             if (col < 0.f) { fl |= (1u << ch); col = 0.f; }
@@ -184,7 +190,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
     mean2d[i] = out_mean;
     depth[i] = out_depth;
     conic_opacity[i] = out_co;
-    rgb[3 * (int64_t)i] = out_rgb[0]; rgb[3 * (int64_t)i + 1] = out_rgb[1]; rgb[3 * (int64_t)i + 2] = out_rgb[2];
+    rgb[i] = make_float4(out_rgb[0], out_rgb[1], out_rgb[2], 0.f);
     flags[i] = out_flags;
     tiles_touched[i] = out_tiles;
     depth_key[i] = out_key;
@@ -205,7 +211,15 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
     const bool valid = i < n;
-    const int radius = valid ? radii[i] : 0;
+    // this lane's own loads go out before the cooperative shN staging so both are in flight together
+    const int il = valid ? i : (n - 1);
+    const int radius = valid ? radii[il] : 0;
+    const float4 in_r0 = grad_rows[3 * (int64_t)il], in_r1 = grad_rows[3 * (int64_t)il + 1], in_r2 = grad_rows[3 * (int64_t)il + 2];
+    const float in_px = pos[3 * (int64_t)il], in_py = pos[3 * (int64_t)il + 1], in_pz = pos[3 * (int64_t)il + 2];
+    const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
+    const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
+    const float in_op = opacity[il];
+    const uint32_t in_fl = flags[il];
     if (deg > 0) {
         stage_rows_in<45>(shN, lds, base, n);
         __syncthreads();
@@ -216,7 +230,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     if (radius > 0) {
-        r0 = grad_rows[3 * (int64_t)i]; r1 = grad_rows[3 * (int64_t)i + 1]; r2 = grad_rows[3 * (int64_t)i + 2];
+        r0 = in_r0; r1 = in_r1; r2 = in_r2;
         // leave the accumulation row zeroed for the next backward (saves a 48 B/splat memset pass per view)
         if (rezero) {
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -225,8 +239,8 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float2 dL_dm = make_float2(r0.x, r0.y);
         const float4 gco = make_float4(r0.z, r0.w, r1.x, r1.y);
         const float dL_dcol[3] = {r1.z, r1.w, r2.x};
-        const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
-        const uint32_t fl = flags[i];
+        const float px = in_px, py = in_py, pz = in_pz;
+        const uint32_t fl = in_fl;
         const float tx = dvs_xform(cam.view, px, py, pz, 0);
         const float ty = dvs_xform(cam.view, px, py, pz, 1);
         const float tz = dvs_xform(cam.view, px, py, pz, 2);
@@ -234,10 +248,8 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float hy = dvs_xform(cam.proj, px, py, pz, 1);
         const float hw = dvs_xform(cam.proj, px, py, pz, 3);
         const float pw = 1.0f / (hw + 0.0000001f);
-        float s[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] = dvs_exp_det(scale[3 * (int64_t)i + k]);
-        const float4 q4 = reinterpret_cast<const float4*>(rot)[i];
+        const float s[3] = {dvs_exp_det(in_s0), dvs_exp_det(in_s1), dvs_exp_det(in_s2)};
+        const float4 q4 = in_q;
         const float qn = dvs_sqrt_rn(((q4.x * q4.x + q4.y * q4.y) + q4.z * q4.z) + q4.w * q4.w);
         const float inv_qn = 1.0f / qn;
         const float qr = q4.x * inv_qn, qx = q4.y * inv_qn, qy = q4.z * inv_qn, qz = q4.w * inv_qn;
@@ -301,7 +313,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 
         // 2. opacity (+ AA)
         float g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f;
-        const float sig = dvs_sigmoid_det(opacity[i]);
+        const float sig = dvs_sigmoid_det(in_op);
         float g_sig = gco.w;
         if (antialias) {
             const float det_orig = cxx * cyy - b * b;
@@ -406,19 +418,12 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     if (valid) {
         if (out_absgrad2d) out_absgrad2d[i] = make_float2(r2.y, r2.z);
         if (out_mean2d) out_mean2d[i] = make_float2(r0.x, r0.y);
-        const int64_t i3 = 3 * (int64_t)i;
         if (ACCUM) {
-            g_pos[i3] += gp[0]; g_pos[i3 + 1] += gp[1]; g_pos[i3 + 2] += gp[2];
-            g_sh0[i3] += gs0[0]; g_sh0[i3 + 1] += gs0[1]; g_sh0[i3 + 2] += gs0[2];
-            g_scale[i3] += gsc[0]; g_scale[i3 + 1] += gsc[1]; g_scale[i3 + 2] += gsc[2];
             g_opacity[i] += g_op;
             float4 o = reinterpret_cast<float4*>(g_rot)[i];
             o.x += gq_out[0]; o.y += gq_out[1]; o.z += gq_out[2]; o.w += gq_out[3];
             reinterpret_cast<float4*>(g_rot)[i] = o;
         } else {
-            g_pos[i3] = gp[0]; g_pos[i3 + 1] = gp[1]; g_pos[i3 + 2] = gp[2];
-            g_sh0[i3] = gs0[0]; g_sh0[i3 + 1] = gs0[1]; g_sh0[i3 + 2] = gs0[2];
-            g_scale[i3] = gsc[0]; g_scale[i3 + 1] = gsc[1]; g_scale[i3 + 2] = gsc[2];
             g_opacity[i] = g_op;
             reinterpret_cast<float4*>(g_rot)[i] = make_float4(gq_out[0], gq_out[1], gq_out[2], gq_out[3]);
         }
@@ -429,6 +434,17 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     }
     __syncthreads();
     stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
+    // the three 3-float groups take the same route (a lane-strided 4-byte store would touch every line three times)
+    __syncthreads();
+    float* l_pos = lds, *l_sh0 = lds + PP_BLOCK * 3, *l_scl = lds + PP_BLOCK * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        l_pos[threadIdx.x * 3 + k] = gp[k]; l_sh0[threadIdx.x * 3 + k] = gs0[k]; l_scl[threadIdx.x * 3 + k] = gsc[k];
+    }
+    __syncthreads();
+    stage_rows_out<3, ACCUM>(g_pos, l_pos, base, n);
+    stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
+    stage_rows_out<3, ACCUM>(g_scale, l_scl, base, n);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -441,7 +457,7 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, sh0, shN, opacity, scale, rot, cam,
-                       deg, antialias, tiles_x, tiles_y, radii, (float2*)mean2d, depth, (float4*)conic_opacity, rgb, flags,
+                       deg, antialias, tiles_x, tiles_y, radii, (float2*)mean2d, depth, (float4*)conic_opacity, (float4*)rgb, flags,
                        tiles_touched, depth_key, ids);
     return hipGetLastError();
 }

@@ -93,7 +93,7 @@ struct __attribute__((aligned(16))) BatchLds {
 
 __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt,
                                             const float2* __restrict__ mean2d, const float4* __restrict__ conic_opacity,
-                                            const float* __restrict__ rgb, float tile_x0, float tile_y0) {
+                                            const float4* __restrict__ rgb, float tile_x0, float tile_y0) {
     const int t = threadIdx.x;
     uint32_t qm = 0;
     if (t < cnt) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         L.id[t] = id;
         L.xy[t] = xy;
         L.co[t] = co;
-        L.rgb[t] = make_float4(rgb[3 * (size_t)id], rgb[3 * (size_t)id + 1], rgb[3 * (size_t)id + 2], 0.f);
+        L.rgb[t] = rgb[id];
         // The splat can reach alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o), d = pixel - mean.
         // Minimise the convex form q over each quadrant's pixel rectangle (exact: origin inside -> 0, otherwise the
         // minimum lies on one of the four edges) and keep the splat for that quadrant iff the minimum is within the bound.
@@ -138,7 +138,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 __global__ void __launch_bounds__(RB)
 k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ sorted_splat, const float2* __restrict__ mean2d,
-             const float4* __restrict__ conic_opacity, const float* __restrict__ rgb, float bg0, float bg1, float bg2,
+             const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb, float bg0, float bg1, float bg2,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     __shared__ BatchLds L;
     const int tile = tile_of_block(blockIdx.x, num_tiles);
@@ -204,7 +204,7 @@ template <bool ABSGRAD>
 __global__ void __launch_bounds__(RB)
 k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ sorted_splat, const float2* __restrict__ mean2d,
-             const float4* __restrict__ conic_opacity, const float* __restrict__ rgb, float bg0, float bg1, float bg2,
+             const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb, float bg0, float bg1, float bg2,
              const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
              float* __restrict__ grow /*[n,12]: mx my ca cb cc op r g b |mx| |my| pad*/) {
     __shared__ BatchLds L;
@@ -317,7 +317,7 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,
-                       (const float2*)mean2d, (const float4*)conic_opacity, rgb, bg[0], bg[1], bg[2], out_color, final_T,
+                       (const float2*)mean2d, (const float4*)conic_opacity, (const float4*)rgb, bg[0], bg[1], bg[2], out_color, final_T,
                        n_contrib);
     return hipGetLastError();
 }
@@ -331,11 +331,11 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
     const int grid = ((num_tiles + 7) >> 3) << 3;
     if (absgrad)
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges,
-                           sorted_splat, (const float2*)mean2d, (const float4*)conic_opacity, rgb, bg[0], bg[1], bg[2], final_T,
+                           sorted_splat, (const float2*)mean2d, (const float4*)conic_opacity, (const float4*)rgb, bg[0], bg[1], bg[2], final_T,
                            n_contrib, dL_dout, grad_rows);
     else
         hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges,
-                           sorted_splat, (const float2*)mean2d, (const float4*)conic_opacity, rgb, bg[0], bg[1], bg[2], final_T,
+                           sorted_splat, (const float2*)mean2d, (const float4*)conic_opacity, (const float4*)rgb, bg[0], bg[1], bg[2], final_T,
                            n_contrib, dL_dout, grad_rows);
     return hipGetLastError();
 }

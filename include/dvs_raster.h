@@ -92,7 +92,7 @@ typedef struct dvs_fwd_state {
     const float*    mean2d;         /* [n,2] pixel coords, pixel i centre = i */
     const float*    depth;          /* [n] view-space z */
     const float*    conic_opacity;  /* [n,4] conic a,b,c + final opacity */
-    const float*    rgb;            /* [n,3] clamped colour */
+    const float*    rgb;            /* [n,4] clamped colour r,g,b + one pad float (16-B rows: one aligned load per gather) */
     const uint32_t* flags;          /* [n] bit0..2 = SH clamp (colour channel <0), bit3 = fx clamped, bit4 = fy clamped */
     const uint32_t* tiles_touched;  /* [n] */
     /* per instance (num_rendered), sorted by (tile, depth, splat id) */
