@@ -13,7 +13,9 @@
 #include "dvs_device.h"
 #include "dvs_kernels.h"
 
+#ifndef PP_BLOCK
 #define PP_BLOCK 256
+#endif
 
 // ---- cooperative row staging: rows of RW floats per splat, block of PP_BLOCK splats ---------------
 // global [n, RW] -> lds[PP_BLOCK * RW]; the row of lane t starts at lds + t*RW (RW odd => conflict-free).
