@@ -1,0 +1,73 @@
+"""Full-size configs on the GPU (BASELINE.json C3 and the C5 stress shape) checked through size-independent properties
+(the oracle is too slow to run at these sizes inside the GPU suite; C3 parity against the oracle is in tools/gpu_diag.py):
+  * per-tile lists are sorted by (depth, splat id) and ranges tile the instance list exactly,
+  * sum(tiles_touched) == T, every instance's tile lies inside its splat's rect,
+  * compositing invariants: 0 <= final_T <= 1, n_contrib <= list length, image finite,
+  * linearity of the backward in dL/drgb, zero rows for culled splats,
+  * determinism of the forward (bit-identical images on a second run).
+"""
+import numpy as np
+import pytest
+import divshot_amd as dv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,n,W,H,soff", [("C3", 1_000_000, 1920, 1080, 0.0), ("C5_shape", 5_000_000, 3840, 2160, -0.6931472)])
+def test_full_size_properties(gpu_device, name, n, W, H, soff):
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=8, scale_log_offset=soff)
+    P = dv.synth_splats(spec)
+    cam = dv.synth_camera(spec, 3)
+    r = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    Pd = params_to_device(P, r.tdev)
+    img = r.forward(Pd, cam, sh_degree=3, absgrad=True)
+    torch.cuda.synchronize()
+    s = r.saved()
+    T = r.num_rendered
+    assert T == int(s["tiles_touched"].astype(np.int64).sum()) and T > n
+    ranges, vals, tiles = s["ranges"].astype(np.int64), s["vals"], s["sorted_tile"]
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert lens.min() >= 0 and lens.sum() == T
+    nz = lens > 0
+    starts = ranges[nz, 0]
+    order = np.argsort(starts)
+    assert starts[order][0] == 0 and np.array_equal(starts[order][1:], ranges[nz, 1][order][:-1])     # ranges tile [0,T)
+    assert np.array_equal(tiles[ranges[nz, 0]], np.nonzero(nz)[0])                                       # and name their tile
+    assert (np.diff(tiles.astype(np.int64)) >= 0).all()
+    # within a tile: non-decreasing depth, ties by ascending splat id
+    d = s["depth"][vals].view(np.uint32).astype(np.int64)
+    same = np.diff(tiles.astype(np.int64)) == 0
+    dd = np.diff(d)
+    assert (dd[same] >= 0).all()
+    ties = same & (dd == 0)
+    assert (np.diff(vals.astype(np.int64))[ties] > 0).all()
+    # every instance lies inside its splat's tile rect (recomputed from mean2d / radius)
+    tx_n = (W + 15) // 16
+    m, rad = s["mean2d"][vals], s["radii"][vals].astype(np.float32)
+    tx, ty = (tiles % tx_n).astype(np.float32), (tiles // tx_n).astype(np.float32)
+    assert ((m[:, 0] - rad) / 16 < tx + 1).all() and ((m[:, 0] + rad + 15) / 16 >= tx).all()
+    assert ((m[:, 1] - rad) / 16 < ty + 1).all() and ((m[:, 1] + rad + 15) / 16 >= ty).all()
+    # compositing invariants
+    imgh = img.cpu().numpy()
+    assert np.isfinite(imgh).all() and imgh.min() >= 0.0
+    assert s["final_T"].min() >= 0.0 and s["final_T"].max() <= 1.0
+    ty_n = (H + 15) // 16
+    len_px = np.repeat(np.repeat(lens.reshape(ty_n, tx_n), 16, 0), 16, 1)[:H, :W]
+    assert (s["n_contrib"] <= len_px).all()
+    # determinism of the forward
+    img2 = r.forward(Pd, cam, sh_degree=3, absgrad=True).cpu().numpy()
+    assert np.array_equal(imgh, img2)
+    # backward: linear in the upstream gradient, zero rows for culled splats
+    g1 = torch.from_numpy(np.random.default_rng(1).standard_normal(imgh.shape).astype(np.float32)).to(r.tdev)
+    ga = {k: v.clone() for k, v in r.backward(g1).items()}
+    gb = r.backward(g1 * 2.0)
+    torch.cuda.synchronize()
+    culled = torch.from_numpy(s["radii"] == 0).to(r.tdev)
+    for k in ("pos", "sh0", "shN", "opacity", "scale", "rot"):
+        a, b = ga[k].double(), gb[k].double()
+        rel = float((b - 2 * a).norm() / (2 * a).norm())
+        assert rel < 1e-5, (k, rel)                      # atomics reorder fp32 sums: not bit-exact, but linear to 1e-5
+        assert not bool(ga[k][culled].any()), k
+    r.close()
