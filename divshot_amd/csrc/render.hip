@@ -84,7 +84,8 @@ __device__ __forceinline__ void wave_reduce12(const float v[12], float q[3]) {
 // instruction on a splat that cannot touch its pixels. The bound is inflated (1e-4 rel + 1e-3) so the
 // exact per-pixel alpha test — unchanged — decides every contribution: results are identical to a full walk.
 struct __attribute__((aligned(16))) BatchLds {
-    float4 co[RB];
+    float4 cs[RB];      // (-0.5 log2e a, -log2e b, -0.5 log2e c, opacity): exp(power) = exp2(cs.x dx^2 + cs.y dx dy + cs.z dy^2)
+    float4 co[RB];      // conic a, b, c + opacity as preprocess wrote them (gradient formulas)
     float4 rgb[RB];
     float2 xy[RB];
     uint32_t id[RB];
@@ -103,6 +104,7 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         L.id[t] = id;
         L.xy[t] = xy;
         L.co[t] = co;
+        L.cs[t] = make_float4(-0.72134752044448170f * co.x, -1.4426950408889634f * co.y, -0.72134752044448170f * co.z, co.w);
         L.rgb[t] = rgb[id];
         // The splat can reach alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o), d = pixel - mean.
         // Minimise the convex form q over each quadrant's pixel rectangle (exact: origin inside -> 0, otherwise the
@@ -172,19 +174,21 @@ k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 const int j = lw * 64 + __builtin_ctzll(m);
                 m &= m - 1;
                 const float2 xy = L.xy[j];
-                const float4 co = L.co[j];
+                const float4 cs = L.cs[j];
                 const float4 c = L.rgb[j];
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                const float alpha = fminf(DVS_ALPHA_MAX, co.w * __expf(power));
-                const bool valid = !done && !(power > 0.f) && !(alpha < DVS_ALPHA_MIN);
-                const float test_T = T * (1.f - alpha);
+                // log2 of the Gaussian falloff: p2 = log2e * power (sign unchanged), one v_exp_f32, no extra multiply
+                const float p2 = __builtin_fmaf(cs.z * dy, dy, __builtin_fmaf(cs.y, dy, cs.x * dx) * dx);
+                const float alpha = fminf(DVS_ALPHA_MAX, cs.w * __builtin_amdgcn_exp2f(p2));
+                const bool valid = !done && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
+                const float aT = alpha * T;
+                const float test_T = T - aT;                       // = T (1 - alpha)
                 const bool stop = valid && (test_T < DVS_T_STOP);
                 const bool take = valid && !stop;
                 done = done || stop;
-                const float w = take ? alpha * T : 0.f;
-                C0 += c.x * w; C1 += c.y * w; C2 += c.z * w;
-                T = take ? test_T : T;
+                const float w = take ? aT : 0.f;
+                C0 = __builtin_fmaf(c.x, w, C0); C1 = __builtin_fmaf(c.y, w, C1); C2 = __builtin_fmaf(c.z, w, C2);
+                T = T - w;
                 last = take ? (uint32_t)(base + j + 1) : last;
             }
         }
@@ -266,16 +270,17 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 const int j = lw * 64 + bit;
                 const uint32_t k = (uint32_t)(base + j);     // 0-based list position; contributor index k+1
                 const float2 xy = L.xy[j];
-                const float4 co = L.co[j];
+                const float4 cs = L.cs[j];
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                const float G = __expf(power);
-                const float oa = co.w * G;
+                const float p2 = __builtin_fmaf(cs.z * dy, dy, __builtin_fmaf(cs.y, dy, cs.x * dx) * dx);   // same expression as the forward
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float oa = cs.w * G;
                 const float alpha = fminf(DVS_ALPHA_MAX, oa);
-                const bool contrib = (k < last) && !(power > 0.f) && !(alpha < DVS_ALPHA_MIN);
+                const bool contrib = (k < last) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
                 if (!__any(contrib)) continue;
                 // predicated: a non-contributing lane runs with alpha = 0 (T, D unchanged, every partial exactly 0)
                 const float4 c = L.rgb[j];
+                const float4 co = L.co[j];
                 const float al = contrib ? alpha : 0.f;
                 const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);        // 1-alpha >= 0.01: v_rcp_f32 (1 ulp) is ample
                 T = T * inv_1ma;

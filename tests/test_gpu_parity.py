@@ -99,29 +99,38 @@ def test_pipeline_parity(rast, oracle_mod, name):
         tainted |= (np.abs(m2[:, 0] - x) <= rad) & (np.abs(m2[:, 1] - y) <= rad) & (rad > 0)
     if not name.startswith("dense"):      # huge splats: one fragile pixel taints everything that covers it
         assert tainted.mean() < 0.10, tainted.mean()
-    if not np.array_equal(o64.get("n_contrib")[~frag_any], nc_ref[~frag_any]) or not np.array_equal(o64.get("vals"), o.get("vals")):
-        tainted[:] = True      # fp64 binned differently (radius at an integer boundary): fp32 oracle everywhere
     ref64 = o64.backward(dL)
     ref32 = o.backward(dL)
+    if not np.array_equal(o64.get("n_contrib")[~frag_any], nc_ref[~frag_any]) or not np.array_equal(o64.get("vals"), o.get("vals")):
+        # fp64 binned differently somewhere (a radius at an integer boundary): the fp32 oracle is the strict reference
+        o64, ref64 = o, ref32
 
-    def mix(name64, a64, a32):
-        out = np.array(a64, np.float64)
-        out[tainted] = a32[tainted]
-        return out
+    # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
+    # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-2 relative L2
+    # of the fp32 oracle (one flipped 1/255-alpha contribution moves a gradient by ~1e-3 of its magnitude).
+    clean = ~tainted
 
-    def check_group(name, got, want):
-        m, worst = rel_close(got, want, 1e-4, 1e-5)
-        assert m.all(), f"{name}: worst {worst}, frac ok {m.mean()}"
-        g64, w64 = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
-        l2 = np.linalg.norm(g64 - w64) / max(np.linalg.norm(w64), 1e-300)
-        assert l2 < 1e-5, f"{name}: relative L2 error {l2}"
+    def check_group(name, got, want64, want32):
+        got = np.asarray(got, np.float64); want64 = np.asarray(want64, np.float64); want32 = np.asarray(want32, np.float64)
+        scale = np.abs(want64).max()
+        if clean.any():
+            g, w = got[clean], want64[clean]
+            err = np.abs(g - w)
+            tol = 1e-4 * np.abs(w) + 1e-5 * scale
+            assert (err <= tol).all(), f"{name}: worst {(err / tol).max()}, frac ok {(err <= tol).mean()}"
+            l2 = np.linalg.norm((g - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-300)
+            assert l2 < 1e-5, f"{name}: relative L2 error {l2}"
+        if tainted.any():
+            g, w = got[tainted], want32[tainted]
+            l2 = np.linalg.norm((g - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-300)
+            assert l2 < 1e-2, f"{name} (tainted set): relative L2 error {l2}"
 
     for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb"):
-        check_group(k, inter[k], mix(k, o64.get(k), o.get(k)))
-    check_group("absgrad", grads["absgrad2d"], mix("absgrad", o64.get("absgrad"), o.get("absgrad")))
-    check_group("mean2d", grads["mean2d"], mix("mean2d", o64.get("dL_dmean2d"), o.get("dL_dmean2d")))
+        check_group(k, inter[k], o64.get(k), o.get(k))
+    check_group("absgrad", grads["absgrad2d"], o64.get("absgrad"), o.get("absgrad"))
+    check_group("mean2d", grads["mean2d"], o64.get("dL_dmean2d"), o.get("dL_dmean2d"))
     for k in KEYS:
-        check_group("grad " + k, grads[k], mix(k, ref64[k], ref32[k]))
+        check_group("grad " + k, grads[k], ref64[k], ref32[k])
     # culled splats get exactly zero rows
     culled = saved["radii"] == 0
     for k in KEYS:
