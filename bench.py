@@ -5,7 +5,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 laun
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
 A step = one pass of the hot path over one batch: every rank renders ONE synthetic view of the
 replicated 1M-splat scene (A2..A7), forms dL/drgb = (rgb - target)/P, runs the backward (A8, A9) and,
-for N>1, sum-all-reduces the 59-float gradient rows over xGMI.  value = N*K / time.
+for N>1, exchanges the 59-float gradient rows over xGMI: by default the factorised exchange of
+divshot_amd/parallel.py (all-reduce of the 11 geometry floats + all-gather of the 3-float colour gradients, SH rows rebuilt
+locally; 56 B/splat on the wire instead of 236), or with --exchange allreduce one sum-all-reduce of all rows.
+value = N*K / time.
 Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
@@ -80,6 +83,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
+    ap.add_argument("--exchange", default="factorised", choices=["factorised", "allreduce"],
+                    help="N>1 gradient exchange: factorised (56 B/splat on the wire) or one all-reduce of all 236 B/splat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
     args = ap.parse_args()
@@ -88,7 +93,7 @@ def main():
     import torch
     import divshot_amd as dv
     from divshot_amd.raster import Rasterizer, params_to_device
-    from divshot_amd.parallel import GradBuffer
+    from divshot_amd.parallel import GradBuffer, FactorisedExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,13 +102,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     dist = None
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev          # (a functional test may oversubscribe one GPU with a gloo group; normally 1 rank = 1 GPU)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        backend = os.environ.get("DVS_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n, W, H, deg, soff = WORKLOADS[args.workload]
     n_cams = max(8, world)
@@ -112,7 +122,7 @@ def main():
     cam = dv.synth_camera(spec, rank % n_cams)    # rank r renders view r
     target = torch.from_numpy(dv.synth_target(spec, rank % n_cams)).to(dev)
     params = params_to_device(P, dev)
-    rast = Rasterizer(local_rank, max_splats=n, max_w=W, max_h=H)
+    rast = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
     # one flat gradient buffer so the exchange is a single large collective (236 B/splat)
     gbuf = GradBuffer(n, dev)
     flat, grads = gbuf.flat, dict(gbuf.views)
@@ -121,12 +131,22 @@ def main():
     out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     inv_P = 1.0 / (W * H)
 
+    factorised = dist is not None and args.exchange == "factorised"
+    if factorised:
+        fx = FactorisedExchange(n, dev, world)
+        grads["dcolor"] = fx.dcolor_local
+        campos_all = np.array([list(dv.synth_camera(spec, r % n_cams).campos) for r in range(world)], np.float32)
+
     def step():
         img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out)
         dL = (img - target) * inv_P
-        rast.backward(dL, grads=grads)
-        if dist is not None:
-            dist.all_reduce(flat)
+        if factorised:
+            rast.backward(dL, grads=grads, factorised_sh=True)
+            fx.exchange(gbuf, rast, params["pos"], campos_all, deg)
+        else:
+            rast.backward(dL, grads=grads)
+            if dist is not None:
+                dist.all_reduce(flat)
 
     for _ in range(args.warmup):
         step()
@@ -163,6 +183,7 @@ def main():
     if dist is not None:
         dist.barrier()
 
+    grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
     if rank == 0:
         st = rast.state
         V = int((torch.from_numpy(rast._d2h(st.radii, (n,), np.int32)) > 0).sum())
@@ -197,9 +218,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, 1 view per GPU per step"
-                                   + (", RCCL all-reduce of 59-float gradient rows" if world > 1 else ""),
+                                   + ((", RCCL exchange of the gradient rows: " + args.exchange) if world > 1 else ""),
                        "views_per_step": world, "absgrad": bool(args.absgrad),
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
+            "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_view": total_bytes,
                          "achieved_GBps_end_to_end": total_bytes / (ms_per_step * 1e-3) / 1e9 if world == 1 else None,

@@ -43,7 +43,7 @@ class FwdState(C.Structure):
 
 class SplatGrads(C.Structure):
     _fields_ = [("pos", C.c_void_p), ("sh0", C.c_void_p), ("shN", C.c_void_p), ("opacity", C.c_void_p),
-                ("scale", C.c_void_p), ("rot", C.c_void_p), ("absgrad2d", C.c_void_p), ("mean2d", C.c_void_p)]
+                ("scale", C.c_void_p), ("rot", C.c_void_p), ("absgrad2d", C.c_void_p), ("mean2d", C.c_void_p), ("dcolor", C.c_void_p)]
 
 
 class SceneSpec(C.Structure):
@@ -59,6 +59,8 @@ _PROTOS = {
                                      C.c_void_p, C.POINTER(FwdState), C.POINTER(C.c_uint64)]),
     "dvs_raster_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
                                       C.c_void_p, C.POINTER(SplatGrads)]),
+    "dvs_sh_grad_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int]),
     "dvs_sort_pairs_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "dvs_export_sorted_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

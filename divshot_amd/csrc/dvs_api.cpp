@@ -270,8 +270,8 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     if (!c->have_fwd || c->st.n != p->n || c->st.width != cam->width || c->st.height != cam->height) {
         g_last_error = "dvs_raster_backward: no matching forward on this context"; return DVS_ERR_STATE;
     }
-    if (p->n > 0 && (!out->pos || !out->sh0 || !out->shN || !out->opacity || !out->scale || !out->rot)) {
-        g_last_error = "dvs_raster_backward: null gradient row pointer"; return DVS_ERR_INVALID;
+    if (p->n > 0 && (!out->pos || !out->opacity || !out->scale || !out->rot || ((!out->sh0 || !out->shN) && !out->dcolor))) {
+        g_last_error = "dvs_raster_backward: null gradient row pointer (sh0/shN may be NULL only when dcolor is given)"; return DVS_ERR_INVALID;
     }
     HIPCHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -292,7 +292,7 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     }
     HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
                                        s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
-                                       out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d,
+                                       out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor,
                                        opts->accumulate, c->keep_rows ? 0 : 1));
     c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
     size_t e3 = tm.mark(); tm.span("preprocess_bwd", e2, e3);
@@ -328,6 +328,16 @@ int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
     if (!c->have_fwd) { g_last_error = "dvs_export_sorted_keys: no forward state"; return DVS_ERR_STATE; }
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(dvs_launch_export_keys((hipStream_t)stream, c->st.num_rendered, c->st.sorted_tile, c->st.sorted_splat, c->st.depth, out_keys));
+    return DVS_OK;
+}
+
+int dvs_sh_grad_combine(dvs_ctx* c, void* stream, int n, const float* pos, int sh_degree, int n_views, const float* campos,
+                        const float* dcolor, float* g_sh0, float* g_shN, int accumulate) {
+    if (!c || n < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || (n > 0 && n_views > 0 && (!pos || !campos || !dcolor || !g_sh0 || !g_shN))) {
+        g_last_error = "dvs_sh_grad_combine: bad argument"; return DVS_ERR_INVALID;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(dvs_launch_sh_grad_combine((hipStream_t)stream, n, pos, sh_degree, n_views, campos, dcolor, g_sh0, g_shN, accumulate));
     return DVS_OK;
 }
 

@@ -15,7 +15,10 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
                                      float* g_pos, float* g_sh0, float* g_shN, float* g_opacity, float* g_scale,
                                      float* g_rot, float* out_absgrad2d /*nullable*/, float* out_mean2d /*nullable*/,
-                                     int accumulate, int rezero_rows);
+                                     float* out_dcolor /*nullable*/, int accumulate, int rezero_rows);
+// g_sh0 / g_shN may be nullptr in dvs_launch_preprocess_bwd (factorised exchange); this rebuilds them from dcolor[n_views,n,3].
+hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
+                                      const float* dcolor, float* g_sh0, float* g_shN, int accumulate);
 
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort_pass needs for n items.

@@ -208,7 +208,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
                  float4* __restrict__ grad_rows /*[n,3] float4: mx my ca cb | cc op r g | b |mx| |my| pad; re-zeroed here*/,
                  float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
                  float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
-                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, int rezero) {
+                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor, int rezero) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
@@ -227,6 +227,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         __syncthreads();
     }
     float gp[3] = {0.f, 0.f, 0.f}, gs0[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq_out[4] = {0.f, 0.f, 0.f, 0.f};
+    float gcol[3] = {0.f, 0.f, 0.f};     // dL/d(colour), zeroed where the colour was clamped: all a peer needs to rebuild the SH rows
     float g_op = 0.f;
     float* row = lds + threadIdx.x * 45;
 
@@ -297,6 +298,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch];
+            gcol[ch] = gc[ch];
             gs0[ch] = bas[0] * gc[ch];
         }
         for (int k = 1; k < ncoef; ++k) {
@@ -430,23 +432,72 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
             reinterpret_cast<float4*>(g_rot)[i] = make_float4(gq_out[0], gq_out[1], gq_out[2], gq_out[3]);
         }
     }
-    // shN gradient rows leave through LDS as coalesced 16-B stores (zero rows when deg == 0)
-    if (deg == 0) {
-        if (valid) for (int e = 0; e < 45; ++e) row[e] = 0.f;
+    // shN gradient rows leave through LDS as coalesced 16-B stores (zero rows when deg == 0); skipped entirely in the
+    // factorised multi-GPU mode (g_shN == nullptr: peers rebuild the rows from dcolor, dvs_sh_grad_combine)
+    if (g_shN) {
+        if (deg == 0) {
+            if (valid) for (int e = 0; e < 45; ++e) row[e] = 0.f;
+        }
+        __syncthreads();
+        stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
     }
+    // the 3-float groups take the same route (a lane-strided 4-byte store would touch every line three times)
     __syncthreads();
-    stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
-    // the three 3-float groups take the same route (a lane-strided 4-byte store would touch every line three times)
-    __syncthreads();
-    float* l_pos = lds, *l_sh0 = lds + PP_BLOCK * 3, *l_scl = lds + PP_BLOCK * 6;
+    float* l_pos = lds, *l_sh0 = lds + PP_BLOCK * 3, *l_scl = lds + PP_BLOCK * 6, *l_col = lds + PP_BLOCK * 9;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         l_pos[threadIdx.x * 3 + k] = gp[k]; l_sh0[threadIdx.x * 3 + k] = gs0[k]; l_scl[threadIdx.x * 3 + k] = gsc[k];
+        l_col[threadIdx.x * 3 + k] = gcol[k];
     }
     __syncthreads();
     stage_rows_out<3, ACCUM>(g_pos, l_pos, base, n);
-    stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
+    if (g_sh0) stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
     stage_rows_out<3, ACCUM>(g_scale, l_scl, base, n);
+    if (out_dcolor) stage_rows_out<3, false>(out_dcolor, l_col, base, n);
+}
+
+// ---- factorised SH gradient: rows from per-view colour gradients -----------------------------------------------------
+// dL/dsh0 = SH_C0 * gc and dL/dshN[k] = basis_k(dir_v) * gc are rank-1 in the 3-float colour gradient gc of a view, so in
+// data-parallel training each GPU only has to all-gather gc (12 B/splat/view) instead of all-reducing the 192-B SH rows;
+// every replica then rebuilds the summed rows locally from its own copy of the positions and the views' camera centres.
+#define COMBINE_MAX_VIEWS 16
+struct CombineViews { float campos[COMBINE_MAX_VIEWS][3]; };
+
+template <bool ACCUM>
+__global__ void __launch_bounds__(PP_BLOCK)
+k_sh_grad_combine(int n, const float* __restrict__ pos, int deg, int n_views, CombineViews views,
+                  const float* __restrict__ dcolor /*[n_views, n, 3]*/, float* __restrict__ g_sh0, float* __restrict__ g_shN) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] + [PP_BLOCK*3]
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int i = (int)(base + threadIdx.x);
+    float* row = lds + threadIdx.x * 45;
+    float* l_sh0 = lds + PP_BLOCK * 45;
+    float acc0[3] = {0.f, 0.f, 0.f};
+    for (int e = 0; e < 45; ++e) row[e] = 0.f;
+    if (i < n) {
+        const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
+        const int ncoef = (deg + 1) * (deg + 1);
+        for (int v = 0; v < n_views; ++v) {
+            const float* gcp = dcolor + ((int64_t)v * n + i) * 3;
+            const float gc[3] = {gcp[0], gcp[1], gcp[2]};
+            if (gc[0] == 0.f && gc[1] == 0.f && gc[2] == 0.f) continue;          // culled / fully clamped in this view
+            const float dxw = px - views.campos[v][0], dyw = py - views.campos[v][1], dzw = pz - views.campos[v][2];
+            const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+            const float inv_dl = 1.0f / dl;
+            float bas[16];
+            dvs_sh_basis(deg, dxw * inv_dl, dyw * inv_dl, dzw * inv_dl, bas);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) acc0[ch] += bas[0] * gc[ch];
+            for (int k = 1; k < ncoef; ++k)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) row[(k - 1) * 3 + ch] += bas[k] * gc[ch];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) l_sh0[threadIdx.x * 3 + k] = acc0[k];
+    __syncthreads();
+    stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
+    stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -468,17 +519,35 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos,
                                      float* g_sh0, float* g_shN, float* g_opacity, float* g_scale, float* g_rot,
-                                     float* out_absgrad2d, float* out_mean2d, int accumulate, int rezero) {
+                                     float* out_absgrad2d, float* out_mean2d, float* out_dcolor, int accumulate, int rezero) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = (size_t)PP_BLOCK * 45 * sizeof(float);
     if (accumulate)
         hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
                            deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,
-                           (float2*)out_absgrad2d, (float2*)out_mean2d, rezero);
+                           (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero);
     else
         hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
                            deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,
-                           (float2*)out_absgrad2d, (float2*)out_mean2d, rezero);
+                           (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero);
+    return hipGetLastError();
+}
+
+hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
+                                      const float* dcolor, float* g_sh0, float* g_shN, int accumulate) {
+    if (n <= 0 || n_views <= 0) return hipSuccess;
+    const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const size_t lds = (size_t)PP_BLOCK * 48 * sizeof(float);
+    int acc = accumulate;
+    for (int v0 = 0; v0 < n_views; v0 += COMBINE_MAX_VIEWS) {           // more than 16 views: chunks, accumulating
+        const int nv = n_views - v0 < COMBINE_MAX_VIEWS ? n_views - v0 : COMBINE_MAX_VIEWS;
+        CombineViews cv;
+        for (int v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) cv.campos[v][k] = campos_host[(size_t)(v0 + v) * 3 + k];
+        const float* dc = dcolor + (size_t)v0 * n * 3;
+        if (acc) hipLaunchKernelGGL(k_sh_grad_combine<true>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, deg, nv, cv, dc, g_sh0, g_shN);
+        else hipLaunchKernelGGL(k_sh_grad_combine<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, deg, nv, cv, dc, g_sh0, g_shN);
+        acc = 1;
+    }
     return hipGetLastError();
 }

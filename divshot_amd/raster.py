@@ -79,8 +79,9 @@ class Rasterizer:
         self.num_rendered = int(T.value)
         return out
 
-    def backward(self, dL_drgb, grads=None, accumulate=False, want_mean2d=False):
-        """dL_drgb: CUDA [3,H,W]. Returns dict of gradient tensors shaped like params (+absgrad2d / mean2d)."""
+    def backward(self, dL_drgb, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
+        """dL_drgb: CUDA [3,H,W]. Returns dict of gradient tensors shaped like params (+absgrad2d / mean2d).
+        factorised_sh=True: the sh0/shN rows are NOT written; grads["dcolor"] [n,3] is (see sh_grad_combine)."""
         assert self.state is not None, "forward first"
         params, cam = self._params, self._cam
         n = params["pos"].shape[0]
@@ -92,15 +93,33 @@ class Rasterizer:
             grads["absgrad2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
         if want_mean2d and "mean2d" not in grads:
             grads["mean2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
-        g = SplatGrads(*[grads[k].data_ptr() for k in PARAM_KEYS],
+        if factorised_sh and "dcolor" not in grads:
+            grads["dcolor"] = torch.empty((n, 3), dtype=torch.float32, device=self.tdev)
+
+        def ptr(k):
+            if factorised_sh and k in ("sh0", "shN"):
+                return None
+            return grads[k].data_ptr()
+        g = SplatGrads(*[ptr(k) for k in PARAM_KEYS],
                        grads["absgrad2d"].data_ptr() if "absgrad2d" in grads else None,
-                       grads["mean2d"].data_ptr() if "mean2d" in grads else None)
+                       grads["mean2d"].data_ptr() if "mean2d" in grads else None,
+                       grads["dcolor"].data_ptr() if factorised_sh else None)
         sp = self._splats(params)
         assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous()
         with torch.cuda.device(self.tdev):
             check(lib.dvs_raster_backward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(cam), C.byref(opts),
                                           dL_drgb.data_ptr(), C.byref(g)), "dvs_raster_backward")
         return grads
+
+    def sh_grad_combine(self, pos, campos, dcolor_all, g_sh0, g_shN, sh_degree, accumulate=False):
+        """g_sh0/g_shN (+)= sum over views of the SH rows implied by dcolor_all [V,n,3]; campos: [V,3] host floats."""
+        campos = np.ascontiguousarray(campos, np.float32)
+        V, n = dcolor_all.shape[0], pos.shape[0]
+        assert campos.shape == (V, 3) and dcolor_all.is_contiguous() and dcolor_all.shape == (V, n, 3)
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_sh_grad_combine(self.ctx, _stream_ptr(), n, pos.data_ptr(), sh_degree, V, campos.ctypes.data,
+                                          dcolor_all.data_ptr(), g_sh0.data_ptr(), g_shN.data_ptr(), int(accumulate)),
+                  "dvs_sh_grad_combine")
 
     # -- stage-level access for the parity tests --------------------------------------------------
     def _d2h(self, ptr, shape, dtype):

@@ -118,6 +118,9 @@ typedef struct dvs_splat_grads {
     float* rot;
     float* absgrad2d;   /* [n,2] optional (may be NULL): sum over pixels of |dL/dmean2D| per axis, pixel units */
     float* mean2d;      /* [n,2] optional (may be NULL): dL/dmean2D, pixel units (densification statistic) */
+    float* dcolor;      /* [n,3] optional (may be NULL): dL/d(view-dependent colour), zero where the colour was clamped or the
+                           splat culled. When given, sh0 and shN may be NULL: the SH rows are then NOT written and are rebuilt
+                           later by dvs_sh_grad_combine (factorised data-parallel exchange). Always overwritten. */
 } dvs_splat_grads;
 
 typedef struct dvs_ctx dvs_ctx;
@@ -138,6 +141,14 @@ int dvs_raster_forward(dvs_ctx* ctx, void* stream, const dvs_splats* params, con
  *   dL_drgb: DEVICE [3,H,W] planar fp32.  out: gradient rows (see dvs_splat_grads). Asynchronous. */
 int dvs_raster_backward(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                         const dvs_opts* opts, const float* dL_drgb, const dvs_splat_grads* out);
+
+/* Rebuild SH gradient rows from per-view colour gradients: for every view v and splat i with dir = normalize(pos_i - campos_v):
+ *   g_sh0[i] (+)= SH_C0 * dcolor[v,i],   g_shN[i,k] (+)= basis_k(dir) * dcolor[v,i].
+ * This is exactly what dvs_raster_backward writes into sh0/shN for one view, summed over views; it lets data-parallel ranks
+ * all-gather 12 B/splat/view (dcolor) instead of all-reducing the 192-B SH rows. pos, dcolor [n_views,n,3], g_* are DEVICE
+ * pointers; campos [n_views,3] is a HOST array (camera centres, dvs_camera.campos). accumulate = 0 overwrites the rows. */
+int dvs_sh_grad_combine(dvs_ctx* ctx, void* stream, int n, const float* pos, int sh_degree, int n_views, const float* campos,
+                        const float* dcolor, float* g_sh0, float* g_shN, int accumulate);
 
 /* Stage-level entry points (used by the parity tests and the profiler harness). */
 /* radix sort of (u32 key, u32 value) pairs over key bits [bit_lo, bit_hi), stable, LSD, 8-bit digits.

@@ -165,6 +165,55 @@ def test_accumulate_two_views(rast, oracle_mod):
         assert m.all(), (k, worst)
 
 
+def test_factorised_sh_gradient(rast):
+    """dvs_sh_grad_combine over V views == sum over views of the sh0/shN rows dvs_raster_backward writes:
+    the multi-GPU exchange ships dcolor (12 B/splat/view) instead of the 192-B SH rows."""
+    import torch
+    from divshot_amd.raster import params_to_device
+    from divshot_amd.parallel import GradBuffer, FactorisedExchange
+    spec = dv.make_spec(6000, 160, 120, sh_degree=3, n_cams=4, seed=9)
+    P = dv.synth_splats(spec)
+    Pd = params_to_device(P, rast.tdev)
+    n, V = 6000, 3
+    ref = None
+    gb = GradBuffer(n, rast.tdev)
+    fx = FactorisedExchange(n, rast.tdev, 1)
+    dcol_all = torch.zeros((V, n, 3), dtype=torch.float32, device=rast.tdev)
+    geom_sum = {k: torch.zeros_like(Pd[k]) for k in ("pos", "scale", "rot", "opacity")}
+    campos = []
+    for v in range(V):
+        cam = dv.synth_camera(spec, v + 1)
+        campos.append(list(cam.campos))
+        tgt = torch.from_numpy(dv.synth_target(spec, v + 1)).to(rast.tdev)
+        img = rast.forward(Pd, cam, sh_degree=3)
+        dL = ((img - tgt) / tgt[0].numel()).contiguous()
+        full = rast.backward(dL)
+        if ref is None:
+            ref = {k: full[k].clone() for k in ("sh0", "shN")}
+        else:
+            for k in ref:
+                ref[k] += full[k]
+        fact = rast.backward(dL, grads=dict(gb.views), factorised_sh=True)
+        for k in geom_sum:
+            # geometry rows do not depend on the mode (two backward runs: fp32 atomics reorder sums, so not bit-equal)
+            assert torch.allclose(fact[k], full[k], rtol=1e-4, atol=1e-5 * float(full[k].abs().max())), k
+            geom_sum[k] += full[k]
+        dcol_all[v].copy_(fact["dcolor"])
+    # a single-view cross-check of dcolor itself: sh0 row = SH_C0 * dcolor
+    assert torch.allclose(full["sh0"], 0.28209479177387814 * dcol_all[V - 1], rtol=1e-4, atol=1e-5 * float(full["sh0"].abs().max()))
+    rast.sh_grad_combine(Pd["pos"], np.array(campos, np.float32), dcol_all, gb.views["sh0"], gb.views["shN"], 3)
+    torch.cuda.synchronize()
+    for k in ("sh0", "shN"):
+        m, worst = rel_close(gb.views[k].cpu().numpy(), ref[k].cpu().numpy(), 1e-4, 1e-5)
+        assert m.all(), (k, worst)
+    # accumulate mode adds a second copy
+    rast.sh_grad_combine(Pd["pos"], np.array(campos, np.float32), dcol_all, gb.views["sh0"], gb.views["shN"], 3, accumulate=True)
+    torch.cuda.synchronize()
+    m, worst = rel_close(gb.views["shN"].cpu().numpy(), 2 * ref["shN"].cpu().numpy(), 1e-4, 1e-5)
+    assert m.all(), worst
+    assert fx.dcolor_all.shape == (1, n, 3)
+
+
 def test_edge_cases(rast, oracle_mod):
     """empty scene, everything culled, one splat on a tile corner, a splat covering the whole image
     (wave-cooperative duplication), a pixel stack that saturates (T < 1e-4), tile lists > 256 entries."""

@@ -34,6 +34,41 @@ def _worker(rank, world, port, n, out):
     dist.destroy_process_group()
 
 
+def _worker_fact(rank, world, port, n, out):
+    sys.path.insert(0, ROOT)
+    from divshot_amd.parallel import GradBuffer, FactorisedExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gb = GradBuffer(n, torch.device("cpu"))
+    fx = FactorisedExchange(n, torch.device("cpu"), world)
+    gb.flat_geom += (rank + 1) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+    gb.flat_sh.fill_(-1.0)                                   # must not be touched by the communication
+    fx.dcolor_local.copy_((rank + 1) * torch.ones((n, 3)) + torch.arange(n, dtype=torch.float32)[:, None])
+    fx.communicate(gb)
+    want = sum(range(1, world + 1)) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+    assert torch.allclose(gb.flat_geom, want, rtol=1e-6)
+    assert bool((gb.flat_sh == -1.0).all())
+    for r in range(world):                                   # gathered in rank order
+        assert torch.equal(fx.dcolor_all[r], (r + 1) * torch.ones((n, 3)) + torch.arange(n, dtype=torch.float32)[:, None])
+    out.put((rank, float(gb.flat_geom.sum())))
+    dist.destroy_process_group()
+
+
+def test_factorised_exchange_communication_gloo():
+    world, n = 2, 193
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fact, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sums = dict(out.get(timeout=5) for _ in range(world))
+    assert abs(sums[0] - sums[1]) < 1e-3 * abs(sums[0])
+
+
 def test_view_sharding():
     from divshot_amd.parallel import views_for_rank
     for world in (1, 2, 4, 8):
@@ -47,7 +82,10 @@ def test_grad_buffer_layout():
     gb = GradBuffer(10, torch.device("cpu"))
     assert ROW_FLOATS == 59 and gb.flat.numel() == 590          # 59 fp32 = 236 B per splat (editor.cpp:1578)
     gb.views["rot"][3, 2] = 7.0
-    assert gb.flat[10 * (3 + 3 + 45 + 1 + 3) + 3 * 4 + 2] == 7.0
+    assert gb.flat[10 * (3 + 3) + 3 * 4 + 2] == 7.0             # flat order: pos, scale, rot, opacity | sh0, shN
+    assert gb.flat_geom.numel() == 110 and gb.flat_sh.numel() == 480
+    gb.views["shN"][9, 14, 2] = 3.0
+    assert gb.flat[-1] == 3.0
     assert gb.all_reduce() is None                              # no process group: single-GPU path is a no-op
 
 
