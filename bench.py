@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
     ap.add_argument("--exchange", default="factorised", choices=["factorised", "allreduce"],
                     help="N>1 gradient exchange: factorised (56 B/splat on the wire) or one all-reduce of all 236 B/splat")
+    ap.add_argument("--shn-tiled", type=int, default=1,
+                    help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
     args = ap.parse_args()
@@ -123,8 +125,11 @@ def main():
     target = torch.from_numpy(dv.synth_target(spec, rank % n_cams)).to(dev)
     params = params_to_device(P, dev)
     rast = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
+    tiled = bool(args.shn_tiled)
+    if tiled:       # training-loop layout of the 45 higher-order SH floats (DVS_SHN_TILED); converted once, outside the timed region
+        params["shN"] = rast.shn_relayout(params["shN"], n, to_tiled=True)
     # one flat gradient buffer so the exchange is a single large collective (236 B/splat)
-    gbuf = GradBuffer(n, dev)
+    gbuf = GradBuffer(n, dev, shn_tiled=tiled)
     flat, grads = gbuf.flat, dict(gbuf.views)
     if args.absgrad:
         grads["absgrad2d"] = torch.zeros((n, 2), dtype=torch.float32, device=dev)
@@ -138,11 +143,11 @@ def main():
         campos_all = np.array([list(dv.synth_camera(spec, r % n_cams).campos) for r in range(world)], np.float32)
 
     def step():
-        img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out)
+        img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
         dL = (img - target) * inv_P
         if factorised:
             rast.backward(dL, grads=grads, factorised_sh=True)
-            fx.exchange(gbuf, rast, params["pos"], campos_all, deg)
+            fx.exchange(gbuf, rast, params["pos"], campos_all, deg, shn_tiled=tiled)
         else:
             rast.backward(dL, grads=grads)
             if dist is not None:
@@ -173,7 +178,7 @@ def main():
         rast.enable_timing(True)
         acc = {}
         for _ in range(args.profile_iters):
-            img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out)
+            img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
             dL = (img - target) * inv_P
             rast.backward(dL, grads=grads)
             for k, v in rast.stage_timing().items():
@@ -219,7 +224,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, 1 view per GPU per step"
                                    + ((", RCCL exchange of the gradient rows: " + args.exchange) if world > 1 else ""),
-                       "views_per_step": world, "absgrad": bool(args.absgrad),
+                       "views_per_step": world, "absgrad": bool(args.absgrad), "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,

@@ -30,7 +30,8 @@ class Camera(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("sh_degree", C.c_int32), ("antialias", C.c_int32), ("absgrad", C.c_int32), ("accumulate", C.c_int32)]
+    _fields_ = [("sh_degree", C.c_int32), ("antialias", C.c_int32), ("absgrad", C.c_int32), ("accumulate", C.c_int32),
+                ("shn_layout", C.c_int32), ("_reserved", C.c_int32 * 3)]
 
 
 class FwdState(C.Structure):
@@ -60,7 +61,8 @@ _PROTOS = {
     "dvs_raster_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
                                       C.c_void_p, C.POINTER(SplatGrads)]),
     "dvs_sh_grad_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_int]),
+                                      C.c_void_p, C.c_int, C.c_int]),
+    "dvs_shn_relayout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "dvs_sort_pairs_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]),
     "dvs_export_sorted_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

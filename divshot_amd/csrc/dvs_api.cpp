@@ -184,7 +184,8 @@ void dvs_destroy(dvs_ctx* c) {
 int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
                        float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered) {
     if (!c || !p || !cam || !opts || !out_rgb) { g_last_error = "dvs_raster_forward: null argument"; return DVS_ERR_INVALID; }
-    if (p->n < 0 || cam->width <= 0 || cam->height <= 0 || opts->sh_degree < 0 || opts->sh_degree > 3) {
+    if (p->n < 0 || cam->width <= 0 || cam->height <= 0 || opts->sh_degree < 0 || opts->sh_degree > 3 ||
+        (opts->shn_layout != DVS_SHN_ROWS && opts->shn_layout != DVS_SHN_TILED)) {
         g_last_error = "dvs_raster_forward: bad n / image size / sh_degree"; return DVS_ERR_INVALID;
     }
     if ((size_t)p->n > c->max_splats || cam->width > c->max_w || cam->height > c->max_h) {
@@ -205,7 +206,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
                                        opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->mean2d.as<float>(),
                                        c->depth.as<float>(), c->conic_opacity.as<float>(), c->rgb.as<float>(),
                                        c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
-                                       c->ids[0].as<uint32_t>()));
+                                       c->ids[0].as<uint32_t>(), opts->shn_layout));
     size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
     // A5 (low 32 key bits): depth sort over splats, 4 x 8-bit LSD passes
     int cur = 0;
@@ -293,7 +294,7 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
                                        s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
                                        out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor,
-                                       opts->accumulate, c->keep_rows ? 0 : 1));
+                                       opts->accumulate, c->keep_rows ? 0 : 1, opts->shn_layout));
     c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
     size_t e3 = tm.mark(); tm.span("preprocess_bwd", e2, e3);
     if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, true); }
@@ -331,13 +332,20 @@ int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
     return DVS_OK;
 }
 
+int dvs_shn_relayout(dvs_ctx* c, void* stream, int n, const float* src, float* dst, int to_tiled) {
+    if (!c || n < 0 || (n > 0 && (!src || !dst))) { g_last_error = "dvs_shn_relayout: bad argument"; return DVS_ERR_INVALID; }
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(dvs_launch_shn_relayout((hipStream_t)stream, n, src, dst, to_tiled));
+    return DVS_OK;
+}
+
 int dvs_sh_grad_combine(dvs_ctx* c, void* stream, int n, const float* pos, int sh_degree, int n_views, const float* campos,
-                        const float* dcolor, float* g_sh0, float* g_shN, int accumulate) {
+                        const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_layout) {
     if (!c || n < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || (n > 0 && n_views > 0 && (!pos || !campos || !dcolor || !g_sh0 || !g_shN))) {
         g_last_error = "dvs_sh_grad_combine: bad argument"; return DVS_ERR_INVALID;
     }
     HIPCHECK(hipSetDevice(c->device));
-    HIPCHECK(dvs_launch_sh_grad_combine((hipStream_t)stream, n, pos, sh_degree, n_views, campos, dcolor, g_sh0, g_shN, accumulate));
+    HIPCHECK(dvs_launch_sh_grad_combine((hipStream_t)stream, n, pos, sh_degree, n_views, campos, dcolor, g_sh0, g_shN, accumulate, shn_layout));
     return DVS_OK;
 }
 

@@ -9,16 +9,18 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* mean2d,
                                      float* depth, float* conic_opacity, float* rgb, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids);
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
                                      float* g_pos, float* g_sh0, float* g_shN, float* g_opacity, float* g_scale,
                                      float* g_rot, float* out_absgrad2d /*nullable*/, float* out_mean2d /*nullable*/,
-                                     float* out_dcolor /*nullable*/, int accumulate, int rezero_rows);
+                                     float* out_dcolor /*nullable*/, int accumulate, int rezero_rows, int shn_tiled);
 // g_sh0 / g_shN may be nullptr in dvs_launch_preprocess_bwd (factorised exchange); this rebuilds them from dcolor[n_views,n,3].
 hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
-                                      const float* dcolor, float* g_sh0, float* g_shN, int accumulate);
+                                      const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled);
+// reference rows [n][45] <-> tiled [ceil(n/64)][45][64]
+hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, float* dst, int to_tiled);
 
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort_pass needs for n items.

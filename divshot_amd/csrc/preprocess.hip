@@ -59,7 +59,14 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ g, const floa
     }
 }
 
+// shN layouts. ROWS: [n][45] (the reference's hand-off layout, gaussian_model.cpp:163-167) — rows are moved through LDS.
+// TILED: [ceil(n/64)][12][64][4] — a splat's 45 floats padded to 48 = twelve float4 chunks; chunk c of the 64 splats of a
+// tile is one contiguous 1-KiB run, so a wave reads/writes it with ONE 16-B-per-lane instruction, no LDS round trip
+// (and no LDS-bound occupancy). Element e of splat i: float4 index ((i>>6)*12 + e/4)*64 + (i&63), component e%4.
+__device__ __forceinline__ int64_t shn_tiled_f4(int i, int c) { return ((int64_t)(i >> 6) * 12 + c) * 64 + (i & 63); }
+
 // ---- A2 ---------------------------------------------------------------------------------------
+template <bool TILED>
 __global__ void __launch_bounds__(PP_BLOCK)
 k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__ sh0, const float* __restrict__ shN,
                  const float* __restrict__ opacity, const float* __restrict__ scale, const float* __restrict__ rot,
@@ -77,7 +84,14 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
     const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
     const float in_op = opacity[il];
     const float in_dc0 = sh0[3 * (int64_t)il], in_dc1 = sh0[3 * (int64_t)il + 1], in_dc2 = sh0[3 * (int64_t)il + 2];
-    if (deg > 0) {
+    float4 in_q4[12];                         // TILED: the splat's twelve float4 chunks, requested up front with everything else
+    if (TILED) {
+        const float4* t4 = reinterpret_cast<const float4*>(shN);
+        const int nchunk = (((deg + 1) * (deg + 1) - 1) * 3 + 3) >> 2;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) in_q4[c] = c < nchunk ? t4[shn_tiled_f4(il, c)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!TILED && deg > 0) {
         stage_rows_in<45>(shN, lds, base, n);
         __syncthreads();
     }
@@ -169,13 +183,31 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         float bas[16];
         dvs_sh_basis(deg, dx * inv_dl, dy * inv_dl, dz * inv_dl, bas);
         const int ncoef = (deg + 1) * (deg + 1);
-        const float* row = lds + threadIdx.x * 45;
         const float in_dc[3] = {in_dc0, in_dc1, in_dc2};
+        float colr[3] = {bas[0] * in_dc[0], bas[0] * in_dc[1], bas[0] * in_dc[2]};
+        if (TILED) {
+            const int nchunk = ((ncoef - 1) * 3 + 3) >> 2;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                if (c < nchunk) {
+                    const float4 q = in_q4[c];
+                    const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = c * 4 + u;                     // compile-time: coefficient e/3 + 1, channel e%3
+                        if (e < 45 && e / 3 + 1 < ncoef) colr[e % 3] = colr[e % 3] + bas[e / 3 + 1] * qv[u];
+                    }
+                }
+            }
+        } else {
+            const float* row = lds + threadIdx.x * 45;
+            for (int k = 1; k < ncoef; ++k)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) colr[ch] = colr[ch] + bas[k] * row[(k - 1) * 3 + ch];
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float col = bas[0] * in_dc[ch];
-            for (int k = 1; k < ncoef; ++k) col = col + bas[k] * row[(k - 1) * 3 + ch];
-            col = col + 0.5f;
+            float col = colr[ch] + 0.5f;
             if (col < 0.f) { fl |= (1u << ch); col = 0.f; }
             out_rgb[ch] = col;
         }
@@ -200,7 +232,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
 }
 
 // ---- A9 ---------------------------------------------------------------------------------------
-template <bool ACCUM>
+template <bool ACCUM, bool TILED>
 __global__ void __launch_bounds__(PP_BLOCK)
 k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
                  const float* __restrict__ scale, const float* __restrict__ rot, DvsCam cam, int deg, int antialias,
@@ -222,14 +254,18 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
     const float in_op = opacity[il];
     const uint32_t in_fl = flags[il];
-    if (deg > 0) {
+    if (!TILED && deg > 0) {
         stage_rows_in<45>(shN, lds, base, n);
         __syncthreads();
     }
     float gp[3] = {0.f, 0.f, 0.f}, gs0[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq_out[4] = {0.f, 0.f, 0.f, 0.f};
     float gcol[3] = {0.f, 0.f, 0.f};     // dL/d(colour), zeroed where the colour was clamped: all a peer needs to rebuild the SH rows
     float g_op = 0.f;
+    // ROWS: the staged parameter row is overwritten in place by its gradient and leaves through LDS.
+    // TILED: parameters are read from, and gradients written to, the tiled arrays directly.
     float* row = lds + threadIdx.x * 45;
+    const float4* p4 = reinterpret_cast<const float4*>(shN);
+    float4* g4 = reinterpret_cast<float4*>(g_shN);
 
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     if (radius > 0) {
@@ -301,15 +337,42 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
             gcol[ch] = gc[ch];
             gs0[ch] = bas[0] * gc[ch];
         }
-        for (int k = 1; k < ncoef; ++k) {
+        if (TILED) {
+            // twelve float4 chunks: load the parameters of chunk c, emit its four gradient elements, store — nothing is staged
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float coef = row[(k - 1) * 3 + ch];
-                row[(k - 1) * 3 + ch] = bas[k] * gc[ch];       // overwrite the staged parameter with its gradient
-                gdir[0] += dbas[k][0] * coef * gc[ch]; gdir[1] += dbas[k][1] * coef * gc[ch]; gdir[2] += dbas[k][2] * coef * gc[ch];
+            for (int c = 0; c < 12; ++c) {
+                const int64_t idx = shn_tiled_f4(i, c);
+                float gv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (c * 4 < (ncoef - 1) * 3) {
+                    const float4 q = p4[idx];
+                    const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = c * 4 + u;                     // compile-time: coefficient k = e/3 + 1, channel e%3
+                        if (e < 45 && e / 3 + 1 < ncoef) {
+                            const int k = e / 3 + 1, ch = e % 3;
+                            gv[u] = bas[k] * gc[ch];
+                            gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                        }
+                    }
+                }
+                if (g4) {
+                    float4 o = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                    if (ACCUM) { const float4 p = g4[idx]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                    g4[idx] = o;
+                }
             }
+        } else {
+            for (int k = 1; k < ncoef; ++k) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float coef = row[(k - 1) * 3 + ch];
+                    row[(k - 1) * 3 + ch] = bas[k] * gc[ch];       // overwrite the staged parameter with its gradient
+                    gdir[0] += dbas[k][0] * coef * gc[ch]; gdir[1] += dbas[k][1] * coef * gc[ch]; gdir[2] += dbas[k][2] * coef * gc[ch];
+                }
+            }
+            for (int e = (ncoef - 1) * 3; e < 45; ++e) row[e] = 0.f;
         }
-        for (int e = (ncoef - 1) * 3; e < 45; ++e) row[e] = 0.f;
         {
             const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
             gp[0] += (gdir[0] - ux * ug) * inv_dl; gp[1] += (gdir[1] - uy * ug) * inv_dl; gp[2] += (gdir[2] - uz * ug) * inv_dl;
@@ -416,7 +479,14 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         gq_out[0] = (gq[0] - qr * qg) * inv_qn; gq_out[1] = (gq[1] - qx * qg) * inv_qn;
         gq_out[2] = (gq[2] - qy * qg) * inv_qn; gq_out[3] = (gq[3] - qz * qg) * inv_qn;
     } else if (valid) {
-        for (int e = 0; e < 45; ++e) row[e] = 0.f;
+        if (TILED) {
+            if (g4 && !ACCUM) {
+#pragma unroll
+                for (int c = 0; c < 12; ++c) g4[shn_tiled_f4(i, c)] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (int e = 0; e < 45; ++e) row[e] = 0.f;
+        }
     }
 
     if (valid) {
@@ -434,7 +504,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     }
     // shN gradient rows leave through LDS as coalesced 16-B stores (zero rows when deg == 0); skipped entirely in the
     // factorised multi-GPU mode (g_shN == nullptr: peers rebuild the rows from dcolor, dvs_sh_grad_combine)
-    if (g_shN) {
+    if (!TILED && g_shN) {
         if (deg == 0) {
             if (valid) for (int e = 0; e < 45; ++e) row[e] = 0.f;
         }
@@ -463,7 +533,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 #define COMBINE_MAX_VIEWS 16
 struct CombineViews { float campos[COMBINE_MAX_VIEWS][3]; };
 
-template <bool ACCUM>
+template <bool ACCUM, bool TILED>
 __global__ void __launch_bounds__(PP_BLOCK)
 k_sh_grad_combine(int n, const float* __restrict__ pos, int deg, int n_views, CombineViews views,
                   const float* __restrict__ dcolor /*[n_views, n, 3]*/, float* __restrict__ g_sh0, float* __restrict__ g_shN) {
@@ -495,9 +565,60 @@ k_sh_grad_combine(int n, const float* __restrict__ pos, int deg, int n_views, Co
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) l_sh0[threadIdx.x * 3 + k] = acc0[k];
-    __syncthreads();
-    stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
+    if (TILED) {
+        if (i < n) {
+            float4* d4 = reinterpret_cast<float4*>(g_shN);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                float4 o = c == 11 ? make_float4(row[44], 0.f, 0.f, 0.f)          // chunk 11 holds element 44 and three pads
+                                   : make_float4(row[c * 4], row[c * 4 + 1], row[c * 4 + 2], row[c * 4 + 3]);
+                const int64_t idx = shn_tiled_f4(i, c);
+                if (ACCUM) { const float4 p = d4[idx]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                d4[idx] = o;
+            }
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
+    }
     stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
+}
+
+// ---- relayout between the reference rows [n][45] and the tiled layout --------------------------------------------------
+__global__ void __launch_bounds__(PP_BLOCK)
+k_shn_relayout(int n, const float* __restrict__ src, float* __restrict__ dst, int to_tiled) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int i = (int)(base + threadIdx.x);
+    float* row = lds + threadIdx.x * 45;
+    if (to_tiled) {
+        stage_rows_in<45>(src, lds, base, n);
+        __syncthreads();
+        // pad lanes of the last tile and the 3 pad floats of every splat are written as zero: the tiled array is fully defined
+        if ((i >> 6) < ((n + 63) >> 6)) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n) o = c == 11 ? make_float4(row[44], 0.f, 0.f, 0.f)
+                                       : make_float4(row[c * 4], row[c * 4 + 1], row[c * 4 + 2], row[c * 4 + 3]);
+                d4[shn_tiled_f4(i, c)] = o;
+            }
+        }
+    } else {
+        if (i < n) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const float4 q = s4[shn_tiled_f4(i, c)];
+                row[c * 4] = q.x;
+                if (c < 11) { row[c * 4 + 1] = q.y; row[c * 4 + 2] = q.z; row[c * 4 + 3] = q.w; }
+            }
+        }
+        __syncthreads();
+        stage_rows_out<45, false>(dst, lds, base, n);
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -505,13 +626,19 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* mean2d,
                                      float* depth, float* conic_opacity, float* rgb, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids) {
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
-    const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;
-    hipLaunchKernelGGL(k_preprocess_fwd, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, sh0, shN, opacity, scale, rot, cam,
-                       deg, antialias, tiles_x, tiles_y, radii, (float2*)mean2d, depth, (float4*)conic_opacity, (float4*)rgb, flags,
-                       tiles_touched, depth_key, ids);
+    if (shn_tiled) {
+        hipLaunchKernelGGL(k_preprocess_fwd<true>, dim3(grid), dim3(PP_BLOCK), 0, st, n, pos, sh0, shN, opacity, scale, rot, cam,
+                           deg, antialias, tiles_x, tiles_y, radii, (float2*)mean2d, depth, (float4*)conic_opacity, (float4*)rgb, flags,
+                           tiles_touched, depth_key, ids);
+    } else {
+        const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;
+        hipLaunchKernelGGL(k_preprocess_fwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, sh0, shN, opacity, scale, rot, cam,
+                           deg, antialias, tiles_x, tiles_y, radii, (float2*)mean2d, depth, (float4*)conic_opacity, (float4*)rgb, flags,
+                           tiles_touched, depth_key, ids);
+    }
     return hipGetLastError();
 }
 
@@ -519,23 +646,24 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos,
                                      float* g_sh0, float* g_shN, float* g_opacity, float* g_scale, float* g_rot,
-                                     float* out_absgrad2d, float* out_mean2d, float* out_dcolor, int accumulate, int rezero) {
+                                     float* out_absgrad2d, float* out_mean2d, float* out_dcolor, int accumulate, int rezero,
+                                     int shn_tiled) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
-    const size_t lds = (size_t)PP_BLOCK * 45 * sizeof(float);
-    if (accumulate)
-        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
-                           deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,
-                           (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero);
-    else
-        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam,
-                           deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,
-                           (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero);
+    // ROWS: 45 floats per lane of staging; TILED: only the four 3-float groups go through LDS
+    const size_t lds = (size_t)PP_BLOCK * (shn_tiled ? 12 : 45) * sizeof(float);
+#define DVS_PPB(A, T)                                                                                                        \
+    hipLaunchKernelGGL((k_preprocess_bwd<A, T>), dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam, deg, \
+                       antialias, radii, flags, (float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,           \
+                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero)
+    if (accumulate) { if (shn_tiled) DVS_PPB(true, true); else DVS_PPB(true, false); }
+    else { if (shn_tiled) DVS_PPB(false, true); else DVS_PPB(false, false); }
+#undef DVS_PPB
     return hipGetLastError();
 }
 
 hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
-                                      const float* dcolor, float* g_sh0, float* g_shN, int accumulate) {
+                                      const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled) {
     if (n <= 0 || n_views <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = (size_t)PP_BLOCK * 48 * sizeof(float);
@@ -545,9 +673,18 @@ hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, i
         CombineViews cv;
         for (int v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) cv.campos[v][k] = campos_host[(size_t)(v0 + v) * 3 + k];
         const float* dc = dcolor + (size_t)v0 * n * 3;
-        if (acc) hipLaunchKernelGGL(k_sh_grad_combine<true>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, deg, nv, cv, dc, g_sh0, g_shN);
-        else hipLaunchKernelGGL(k_sh_grad_combine<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, deg, nv, cv, dc, g_sh0, g_shN);
+#define DVS_CMB(A, T) hipLaunchKernelGGL((k_sh_grad_combine<A, T>), dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, deg, nv, cv, dc, g_sh0, g_shN)
+        if (acc) { if (shn_tiled) DVS_CMB(true, true); else DVS_CMB(true, false); }
+        else { if (shn_tiled) DVS_CMB(false, true); else DVS_CMB(false, false); }
+#undef DVS_CMB
         acc = 1;
     }
+    return hipGetLastError();
+}
+
+hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, float* dst, int to_tiled) {
+    if (n <= 0) return hipSuccess;
+    const int grid = (((n + 63) / 64) * 64 + PP_BLOCK - 1) / PP_BLOCK;      // cover the pad lanes of the last tile
+    hipLaunchKernelGGL(k_shn_relayout, dim3(grid), dim3(PP_BLOCK), (size_t)PP_BLOCK * 45 * sizeof(float), st, n, src, dst, to_tiled);
     return hipGetLastError();
 }

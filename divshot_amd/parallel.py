@@ -27,13 +27,15 @@ class GradBuffer:
     """Flat [n*59] gradient buffer with per-group views shaped like the parameter arrays.
     flat_geom = the leading n*11 floats (pos, scale, rot, opacity); flat_sh = the trailing n*48 (sh0, shN)."""
 
-    def __init__(self, n, device):
+    def __init__(self, n, device, shn_tiled=False):
         self.n = n
-        self.flat = torch.zeros(n * ROW_FLOATS, dtype=torch.float32, device=device)
+        shn_floats = ((n + 63) // 64) * 64 * 48 if shn_tiled else n * 45     # DVS_SHN_TILED: whole 64-splat tiles, 48 floats/splat
+        self.flat = torch.zeros(n * (ROW_FLOATS - 45) + shn_floats, dtype=torch.float32, device=device)
         self.views, off = {}, 0
         for k in FLAT_ORDER:
-            cnt = n * PARAM_WIDTH[k]
-            self.views[k] = self.flat[off:off + cnt].view([n if d == -1 else d for d in SHAPES[k]])
+            cnt = shn_floats if k == "shN" else n * PARAM_WIDTH[k]
+            v = self.flat[off:off + cnt]
+            self.views[k] = v if (k == "shN" and shn_tiled) else v.view([n if d == -1 else d for d in SHAPES[k]])
             off += cnt
         assert off == self.flat.numel()
         self.flat_geom = self.flat[: n * GEOM_FLOATS]
@@ -81,7 +83,7 @@ class FactorisedExchange:
             dist.all_gather(list(self.dcolor_all.unbind(0)), self.dcolor_local, group=group)
         work.wait()
 
-    def exchange(self, gbuf, rast, pos, campos_all, sh_degree, group=None):
+    def exchange(self, gbuf, rast, pos, campos_all, sh_degree, group=None, shn_tiled=False):
         """Full exchange: after this, every view of gbuf holds the sum over all ranks' views."""
         self.communicate(gbuf, group)
-        rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree)
+        rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree, shn_tiled=shn_tiled)

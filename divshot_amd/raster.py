@@ -13,6 +13,26 @@ PARAM_KEYS = ("pos", "sh0", "shN", "opacity", "scale", "rot")
 PARAM_WIDTH = {"pos": 3, "sh0": 3, "shN": 45, "opacity": 1, "scale": 3, "rot": 4}
 
 
+def tiled_floats(n):
+    """Number of floats of an shN array in the DVS_SHN_TILED layout ([ceil(n/64)][12][64][4])."""
+    return ((n + 63) // 64) * 64 * 48
+
+
+def shn_rows_to_tiled_np(a):
+    """numpy definition of the tiled layout: [n,15,3] (or [n,45]) -> flat [ceil(n/64)*64*48]."""
+    n = a.shape[0]
+    nt = (n + 63) // 64
+    pad = np.zeros((nt * 64, 48), a.dtype)
+    pad[:n, :45] = a.reshape(n, 45)
+    return np.ascontiguousarray(pad.reshape(nt, 64, 12, 4).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def shn_tiled_to_rows_np(t, n):
+    nt = (n + 63) // 64
+    rows = np.ascontiguousarray(np.asarray(t).reshape(nt, 12, 64, 4).transpose(0, 2, 1, 3)).reshape(nt * 64, 48)
+    return rows[:n, :45].reshape(n, 15, 3)
+
+
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -43,13 +63,21 @@ class Rasterizer:
             pass
 
     # -- helpers ---------------------------------------------------------------------------
-    def _splats(self, params):
+    def _splats(self, params, tiled=False):
         n = params["pos"].shape[0]
         for k in PARAM_KEYS:
             t = params[k]
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), k
-            assert t.numel() == n * PARAM_WIDTH[k], k
+            want = tiled_floats(n) if (tiled and k == "shN") else n * PARAM_WIDTH[k]
+            assert t.numel() == want, (k, t.numel(), want)
         return Splats(*[params[k].data_ptr() for k in PARAM_KEYS], n, 0)
+
+    def shn_relayout(self, src, n, to_tiled):
+        """DEVICE relayout of an shN array between the reference rows [n,45] and the tiled layout (returns a new tensor)."""
+        dst = torch.zeros(tiled_floats(n) if to_tiled else n * 45, dtype=torch.float32, device=self.tdev)
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_shn_relayout(self.ctx, _stream_ptr(), n, src.data_ptr(), dst.data_ptr(), 1 if to_tiled else 0), "dvs_shn_relayout")
+        return dst if to_tiled else dst.view(n, 15, 3)
 
     def keep_intermediates(self, on=True):
         check(lib.dvs_keep_bwd_intermediates(self.ctx, 1 if on else 0))
@@ -64,10 +92,12 @@ class Rasterizer:
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
     # -- the two ops -------------------------------------------------------------------------
-    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None):
-        """params: dict of CUDA float32 tensors (A0 layout). Returns out_rgb [3,H,W] (CUDA)."""
-        sp = self._splats(params)
-        opts = Opts(sh_degree, int(antialias), int(absgrad), 0)
+    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False):
+        """params: dict of CUDA float32 tensors (A0 layout; params["shN"] in the tiled layout when shn_tiled).
+        Returns out_rgb [3,H,W] (CUDA)."""
+        sp = self._splats(params, shn_tiled)
+        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled))
+        self._tiled = bool(shn_tiled)
         if out is None:
             out = torch.empty((3, cam.height, cam.width), dtype=torch.float32, device=self.tdev)
         st = FwdState()
@@ -88,7 +118,7 @@ class Rasterizer:
         if grads is None:
             grads = {k: torch.empty_like(params[k]) for k in PARAM_KEYS}
             accumulate = False
-        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate))
+        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout)
         if self._opts.absgrad and "absgrad2d" not in grads and not accumulate:
             grads["absgrad2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
         if want_mean2d and "mean2d" not in grads:
@@ -104,21 +134,21 @@ class Rasterizer:
                        grads["absgrad2d"].data_ptr() if "absgrad2d" in grads else None,
                        grads["mean2d"].data_ptr() if "mean2d" in grads else None,
                        grads["dcolor"].data_ptr() if factorised_sh else None)
-        sp = self._splats(params)
+        sp = self._splats(params, self._tiled)
         assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous()
         with torch.cuda.device(self.tdev):
             check(lib.dvs_raster_backward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(cam), C.byref(opts),
                                           dL_drgb.data_ptr(), C.byref(g)), "dvs_raster_backward")
         return grads
 
-    def sh_grad_combine(self, pos, campos, dcolor_all, g_sh0, g_shN, sh_degree, accumulate=False):
+    def sh_grad_combine(self, pos, campos, dcolor_all, g_sh0, g_shN, sh_degree, accumulate=False, shn_tiled=False):
         """g_sh0/g_shN (+)= sum over views of the SH rows implied by dcolor_all [V,n,3]; campos: [V,3] host floats."""
         campos = np.ascontiguousarray(campos, np.float32)
         V, n = dcolor_all.shape[0], pos.shape[0]
         assert campos.shape == (V, 3) and dcolor_all.is_contiguous() and dcolor_all.shape == (V, n, 3)
         with torch.cuda.device(self.tdev):
             check(lib.dvs_sh_grad_combine(self.ctx, _stream_ptr(), n, pos.data_ptr(), sh_degree, V, campos.ctypes.data,
-                                          dcolor_all.data_ptr(), g_sh0.data_ptr(), g_shN.data_ptr(), int(accumulate)),
+                                          dcolor_all.data_ptr(), g_sh0.data_ptr(), g_shN.data_ptr(), int(accumulate), int(shn_tiled)),
                   "dvs_sh_grad_combine")
 
     # -- stage-level access for the parity tests --------------------------------------------------

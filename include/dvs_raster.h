@@ -77,11 +77,23 @@ typedef struct dvs_camera {
     float bg[3];
 } dvs_camera;
 
+/* layout of the shN array in dvs_splats AND of the shN rows in dvs_splat_grads */
+enum {
+    DVS_SHN_ROWS = 0,      /* [n][45]: the reference's hand-off layout (gaussian_model.cpp:163-167), element e of splat i at i*45+e */
+    DVS_SHN_TILED = 1      /* [ceil(n/64)][12][64][4]: the 45 floats of a splat padded to 48 = twelve float4 chunks; element e of
+                              splat i at (((i>>6)*12 + e/4)*64 + (i&63))*4 + e%4; ceil(n/64)*64*48 floats (pads are zero).
+                              Chunk c of 64 consecutive splats = one contiguous 1-KiB run: a wave moves it with one 16-B-per-lane
+                              instruction, no LDS round trip. Element-wise consumers (optimizer, all-reduce) are
+                              layout-agnostic; dvs_shn_relayout converts. */
+};
+
 typedef struct dvs_opts {
     int32_t sh_degree;     /* active SH degree 0..3 */
     int32_t antialias;     /* mip-splatting opacity compensation (main.cpp:63 --mipAntiliased; gsplat_vs.hlsl:296-301) */
     int32_t absgrad;       /* also accumulate |dL/dmean2D| (main.cpp:44 --absgrad) */
     int32_t accumulate;    /* backward: 0 = overwrite gradient rows, 1 = add into them (multi-view batches) */
+    int32_t shn_layout;    /* DVS_SHN_ROWS (default 0) or DVS_SHN_TILED */
+    int32_t _reserved[3];
 } dvs_opts;
 
 /* Saved forward state. DEVICE pointers into ctx-owned arenas; valid until the next
@@ -148,7 +160,9 @@ int dvs_raster_backward(dvs_ctx* ctx, void* stream, const dvs_splats* params, co
  * all-gather 12 B/splat/view (dcolor) instead of all-reducing the 192-B SH rows. pos, dcolor [n_views,n,3], g_* are DEVICE
  * pointers; campos [n_views,3] is a HOST array (camera centres, dvs_camera.campos). accumulate = 0 overwrites the rows. */
 int dvs_sh_grad_combine(dvs_ctx* ctx, void* stream, int n, const float* pos, int sh_degree, int n_views, const float* campos,
-                        const float* dcolor, float* g_sh0, float* g_shN, int accumulate);
+                        const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_layout);
+/* Convert an shN array (DEVICE, src != dst) between DVS_SHN_ROWS [n*45] and DVS_SHN_TILED [ceil(n/64)*64*48]. */
+int dvs_shn_relayout(dvs_ctx* ctx, void* stream, int n, const float* src, float* dst, int to_tiled);
 
 /* Stage-level entry points (used by the parity tests and the profiler harness). */
 /* radix sort of (u32 key, u32 value) pairs over key bits [bit_lo, bit_hi), stable, LSD, 8-bit digits.

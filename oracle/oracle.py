@@ -71,7 +71,7 @@ class Oracle:
         """params: dict of numpy arrays (A0 layout); cam: divshot_amd.Camera (ctypes struct, same layout as dvs_camera)."""
         arrs = [np.ascontiguousarray(params[k], dtype=self.dtype) for k in ("pos", "sh0", "shN", "opacity", "scale", "rot")]
         n = arrs[0].shape[0]
-        opts = (C.c_int32 * 4)(sh_degree, int(antialias), int(absgrad), 0)
+        opts = (C.c_int32 * 8)(sh_degree, int(antialias), int(absgrad), 0, 0, 0, 0, 0)
         self.W, self.H = cam.width, cam.height
         rc = self.lib.dvso_forward(self.h, n, *[a.ctypes.data for a in arrs], C.addressof(cam), C.addressof(opts))
         assert rc == 0

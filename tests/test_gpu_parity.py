@@ -214,6 +214,55 @@ def test_factorised_sh_gradient(rast):
     assert fx.dcolor_all.shape == (1, n, 3)
 
 
+def test_tiled_shn_layout(rast):
+    """DVS_SHN_TILED ([ceil(n/64)][45][64]) is a pure relayout: same image bit for bit, same gradients, for n not a multiple
+    of 64 and for every SH degree; dvs_shn_relayout matches the numpy definition both ways; accumulate and the factorised
+    combine work in the tiled layout too."""
+    import torch
+    from divshot_amd.raster import params_to_device, shn_rows_to_tiled_np, shn_tiled_to_rows_np, tiled_floats
+    n = 5003
+    spec = dv.make_spec(n, 200, 120, sh_degree=3, n_cams=3, seed=21)
+    P = dv.synth_splats(spec)
+    Pd = params_to_device(P, rast.tdev)
+    t_dev = rast.shn_relayout(Pd["shN"], n, to_tiled=True)
+    torch.cuda.synchronize()
+    assert t_dev.numel() == tiled_floats(n)
+    np.testing.assert_array_equal(t_dev.cpu().numpy(), shn_rows_to_tiled_np(P["shN"]))
+    back = rast.shn_relayout(t_dev, n, to_tiled=False)
+    np.testing.assert_array_equal(back.cpu().numpy(), P["shN"])
+    Pt = dict(Pd); Pt["shN"] = t_dev
+    cam = dv.synth_camera(spec, 1)
+    tgt = torch.from_numpy(dv.synth_target(spec, 1)).to(rast.tdev)
+    for deg in (0, 1, 2, 3):
+        img_r = rast.forward(Pd, cam, sh_degree=deg).clone()
+        dL = ((img_r - tgt) / tgt[0].numel()).contiguous()
+        g_r = {k: v.clone() for k, v in rast.backward(dL).items()}
+        img_t = rast.forward(Pt, cam, sh_degree=deg, shn_tiled=True)
+        assert torch.equal(img_r, img_t), deg
+        g_t = rast.backward(dL)
+        torch.cuda.synchronize()
+        assert g_t["shN"].numel() == tiled_floats(n)
+        got = shn_tiled_to_rows_np(g_t["shN"].cpu().numpy(), n)
+        m, worst = rel_close(got, g_r["shN"].cpu().numpy(), 1e-4, 1e-5)
+        assert m.all(), (deg, worst)
+        for k in ("pos", "sh0", "opacity", "scale", "rot"):
+            m, worst = rel_close(g_t[k].cpu().numpy(), g_r[k].cpu().numpy(), 1e-4, 1e-5)
+            assert m.all(), (deg, k, worst)
+    # accumulate in the tiled layout: second backward adds the same rows again
+    acc = {k: v.clone() for k, v in g_t.items() if k in KEYS}
+    rast.backward(dL, grads=acc, accumulate=True)
+    torch.cuda.synchronize()
+    m, worst = rel_close(acc["shN"].cpu().numpy(), 2 * g_t["shN"].cpu().numpy(), 1e-4, 1e-5)
+    assert m.all(), worst
+    # factorised combine into tiled rows
+    fact = rast.backward(dL, factorised_sh=True)
+    sh0 = torch.zeros((n, 3), device=rast.tdev); shn = torch.zeros(tiled_floats(n), device=rast.tdev)
+    rast.sh_grad_combine(Pd["pos"], np.array([list(cam.campos)], np.float32), fact["dcolor"][None].contiguous(), sh0, shn, 3, shn_tiled=True)
+    torch.cuda.synchronize()
+    m, worst = rel_close(shn.cpu().numpy(), g_t["shN"].cpu().numpy(), 1e-4, 1e-5)
+    assert m.all(), worst
+
+
 def test_edge_cases(rast, oracle_mod):
     """empty scene, everything culled, one splat on a tile corner, a splat covering the whole image
     (wave-cooperative duplication), a pixel stack that saturates (T < 1e-4), tile lists > 256 entries."""
