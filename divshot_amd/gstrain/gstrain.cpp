@@ -83,17 +83,31 @@ struct GaussianTrainerScene::Impl {
         if (ctx) { dvs_destroy(ctx); ctx = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
+    // floats of group g on the device: the 45 higher-order SH floats live in the DVS_SHN_TILED layout (48 per splat,
+    // whole 64-splat tiles); parameters, gradients and Adam moments share it — the optimizer is element-wise.
+    size_t dev_floats(int g) const { return g == P_SHN ? (size_t)((n + 63) / 64) * 64 * 48 : (size_t)n * kWidth[g]; }
+    void upload(int g, const std::vector<float>& host_rows) {
+        if (g != P_SHN) { HIP_OR_THROW(hipMemcpy(d_param[g], host_rows.data(), host_rows.size() * sizeof(float), hipMemcpyHostToDevice)); return; }
+        float* tmp = nullptr;
+        HIP_OR_THROW(hipMalloc((void**)&tmp, host_rows.size() * sizeof(float) + 4));
+        HIP_OR_THROW(hipMemcpy(tmp, host_rows.data(), host_rows.size() * sizeof(float), hipMemcpyHostToDevice));
+        DVS_OR_THROW(dvs_shn_relayout(ctx, stream, n, tmp, d_param[g], 1));
+        HIP_OR_THROW(hipStreamSynchronize(stream));
+        (void)hipFree(tmp);
+    }
     void alloc_params(int count, const std::vector<float> init[6]) {
         n = count;
         for (int g = 0; g < 6; ++g) {
-            const size_t bytes = (size_t)n * kWidth[g] * sizeof(float);
+            const size_t bytes = dev_floats(g) * sizeof(float);
             HIP_OR_THROW(hipMalloc((void**)&d_param[g], bytes ? bytes : 4));
             HIP_OR_THROW(hipMalloc((void**)&d_grad[g], bytes ? bytes : 4));
             HIP_OR_THROW(hipMalloc((void**)&d_m[g], bytes ? bytes : 4));
             HIP_OR_THROW(hipMalloc((void**)&d_v[g], bytes ? bytes : 4));
-            HIP_OR_THROW(hipMemcpy(d_param[g], init[g].data(), bytes, hipMemcpyHostToDevice));
+            HIP_OR_THROW(hipMemset(d_param[g], 0, bytes));
+            HIP_OR_THROW(hipMemset(d_grad[g], 0, bytes));      // pad lanes of the last tile are never written: keep them zero
             HIP_OR_THROW(hipMemset(d_m[g], 0, bytes));
             HIP_OR_THROW(hipMemset(d_v[g], 0, bytes));
+            upload(g, init[g]);
         }
         HIP_OR_THROW(hipMalloc((void**)&d_absgrad, (size_t)n * 2 * sizeof(float) + 4));
     }
@@ -108,8 +122,17 @@ struct GaussianTrainerScene::Impl {
         if (host_valid) return;
         HIP_OR_THROW(hipStreamSynchronize(stream));
         for (int g = 0; g < 6; ++g) {
-            host[g].resize((size_t)n * kWidth[g]);
-            HIP_OR_THROW(hipMemcpy(host[g].data(), d_param[g], host[g].size() * sizeof(float), hipMemcpyDeviceToHost));
+            host[g].resize((size_t)n * kWidth[g]);             // host copies are always in the reference layout (update_from_cpu)
+            const float* src = d_param[g];
+            float* tmp = nullptr;
+            if (g == P_SHN) {
+                HIP_OR_THROW(hipMalloc((void**)&tmp, host[g].size() * sizeof(float) + 4));
+                DVS_OR_THROW(dvs_shn_relayout(ctx, stream, n, d_param[g], tmp, 0));
+                HIP_OR_THROW(hipStreamSynchronize(stream));
+                src = tmp;
+            }
+            HIP_OR_THROW(hipMemcpy(host[g].data(), src, host[g].size() * sizeof(float), hipMemcpyDeviceToHost));
+            if (tmp) (void)hipFree(tmp);
         }
         host_valid = true;
     }
@@ -147,7 +170,7 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_loss, sizeof(float)));
-    dvs_opts opts{sh_max, cfg.mipAntiliased ? 1 : 0, 0, 0};
+    dvs_opts opts{sh_max, cfg.mipAntiliased ? 1 : 0, 0, 0, DVS_SHN_TILED};
     const dvs_splats sp = splats();
     for (int c = 0; c < spec.n_cams; ++c) {
         dvs_camera cam;
@@ -180,8 +203,7 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
             for (int k = 0; k < 3; ++k) init[P_SCALE][3 * i + k] += 0.15f * r.sym();
         }
     }
-    for (int g = 0; g < 6; ++g)
-        HIP_OR_THROW(hipMemcpy(d_param[g], init[g].data(), init[g].size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int g = 0; g < 6; ++g) upload(g, init[g]);
     if (cfg.verbose) logf_("synthetic scene: %d splats, %d cameras @ %dx%d, SH degree %d%s", spec.n, spec.n_cams, W, H, sh_max, resumed ? " (resumed)" : "");
     return true;
 }
@@ -233,7 +255,7 @@ void GaussianTrainerScene::trainStep() {
     const int ci = (int)(m.cam_rng % m.cams.size());
     const int it = m.step + 1;
     const int deg = m.cfg.progressiveTrain ? std::min(m.sh_max, m.step / 1000) : m.sh_max;   // SH bands unlocked every 1000 steps
-    dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0};
+    dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0, DVS_SHN_TILED};
     const dvs_splats sp = m.splats();
     DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, nullptr, nullptr));
     HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, sizeof(float), m.stream));
@@ -247,7 +269,7 @@ void GaussianTrainerScene::trainStep() {
     const float lr_pos = std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
     const float lr[6] = {lr_pos, m.cfg.featurelr, m.cfg.featurelr / 20.f, m.cfg.opacitylr, m.cfg.scalinglr, m.cfg.rotationlr};
     for (int k = 0; k < 6; ++k)
-        DVS_OR_THROW(dvs_adam_step(m.stream, m.d_param[k], m.d_grad[k], m.d_m[k], m.d_v[k], (size_t)m.n * kWidth[k], lr[k], 0.9f, 0.999f,
+        DVS_OR_THROW(dvs_adam_step(m.stream, m.d_param[k], m.d_grad[k], m.d_m[k], m.d_v[k], m.dev_floats(k), lr[k], 0.9f, 0.999f,
                                    1e-15f, it));
     if (m.cfg.verbose && (m.step % 100 == 0))          // same line the editor logs (application/editor/source/editor.cpp:1554)
         logf_("Iteraions %d, loss : %f", m.step, (double)getCurrentLoss());
