@@ -3,12 +3,13 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
-A step = one pass of the hot path over one batch: every rank renders ONE synthetic view of the
-replicated 1M-splat scene (A2..A7), forms dL/drgb = (rgb - target)/P, runs the backward (A8, A9) and,
-for N>1, exchanges the 59-float gradient rows over xGMI: by default the factorised exchange of
+A step = one pass of the hot path over one batch: every rank renders --views-per-step (default 4) independent synthetic
+views of the replicated 1M-splat scene (A2..A7), forms dL/drgb = (rgb - target)/P and runs the backward (A8, A9) for each,
+accumulating the gradient rows; the views of a step are software-pipelined over two rasterizer contexts / HIP streams
+(steps do not overlap). For N>1 the step ends by exchanging the 59-float gradient rows over xGMI: by default the factorised exchange of
 divshot_amd/parallel.py (all-reduce of the 11 geometry floats + all-gather of the 3-float colour gradients, SH rows rebuilt
 locally; 56 B/splat on the wire instead of 236), or with --exchange allreduce one sum-all-reduce of all rows.
-value = N*K / time.
+value = N * views_per_step * K / time  (weak scaling: per-GPU work is fixed).
 Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
@@ -83,8 +84,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
-    ap.add_argument("--exchange", default="factorised", choices=["factorised", "allreduce"],
-                    help="N>1 gradient exchange: factorised (56 B/splat on the wire) or one all-reduce of all 236 B/splat")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
+                    help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
+                         "12 B per splat per view, SH rows rebuilt locally); auto picks the one that puts fewer bytes on the wire")
+    ap.add_argument("--views-per-step", type=int, default=4,
+                    help="independent views each GPU renders per step (pipelined over two contexts when > 1); gradients accumulate")
     ap.add_argument("--shn-tiled", type=int, default=1,
                     help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,40 +122,70 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     n, W, H, deg, soff = WORKLOADS[args.workload]
-    n_cams = max(8, world)
+    VPS = max(1, args.views_per_step)             # views each rank renders per step (its share of the iteration's batch)
+    n_cams = max(8, world * VPS)
     spec = dv.make_spec(n, W, H, sh_degree=deg, n_cams=n_cams, scale_log_offset=soff)
     P = dv.synth_splats(spec)                     # identical replica on every rank (same seed)
-    cam = dv.synth_camera(spec, rank % n_cams)    # rank r renders view r
-    target = torch.from_numpy(dv.synth_target(spec, rank % n_cams)).to(dev)
+    my_views = [(rank * VPS + v) % n_cams for v in range(VPS)]      # rank r renders views r*VPS .. r*VPS+VPS-1
+    cams = [dv.synth_camera(spec, i) for i in my_views]
+    targets = [torch.from_numpy(dv.synth_target(spec, i)).to(dev) for i in my_views]
+    cam, target = cams[0], targets[0]
     params = params_to_device(P, dev)
-    rast = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
+    # Views of one step are independent, so they are software-pipelined over two rasterizer contexts on two HIP streams:
+    # the HBM/latency-bound front of view v+1 (preprocess, sorts) runs under the VALU-bound composite kernels of view v.
+    n_ctx = 2 if VPS > 1 else 1
+    rasts = [Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H) for _ in range(n_ctx)]
+    rast = rasts[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)] if n_ctx > 1 else [torch.cuda.current_stream(dev)]
     tiled = bool(args.shn_tiled)
     if tiled:       # training-loop layout of the 45 higher-order SH floats (DVS_SHN_TILED); converted once, outside the timed region
         params["shN"] = rast.shn_relayout(params["shN"], n, to_tiled=True)
-    # one flat gradient buffer so the exchange is a single large collective (236 B/splat)
+    # one flat gradient buffer so the exchange is a single large collective; the views of a step accumulate into it
     gbuf = GradBuffer(n, dev, shn_tiled=tiled)
     flat, grads = gbuf.flat, dict(gbuf.views)
     if args.absgrad:
         grads["absgrad2d"] = torch.zeros((n, 2), dtype=torch.float32, device=dev)
-    out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
+    out = outs[0]
     inv_P = 1.0 / (W * H)
 
-    factorised = dist is not None and args.exchange == "factorised"
+    exchange = args.exchange
+    if exchange == "auto":      # bytes received per splat per rank: ring all-reduce of B bytes ~ 2 (w-1)/w B; all-gather of b bytes ~ (w-1) b
+        ring = 2.0 * (world - 1) / max(world, 1)
+        exchange = "factorised" if (world - 1) * VPS * 12 + ring * 44 < ring * 236 else "allreduce"
+    factorised = dist is not None and exchange == "factorised"
     if factorised:
-        fx = FactorisedExchange(n, dev, world)
-        grads["dcolor"] = fx.dcolor_local
-        campos_all = np.array([list(dv.synth_camera(spec, r % n_cams).campos) for r in range(world)], np.float32)
+        fx = FactorisedExchange(n, dev, world, views_per_rank=VPS)
+        campos_all = np.array([list(dv.synth_camera(spec, (r * VPS + v) % n_cams).campos) for r in range(world) for v in range(VPS)], np.float32)
+    bwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
+    step_done = torch.cuda.Event()
+    main_stream = torch.cuda.current_stream(dev)
+    torch.cuda.synchronize()
 
     def step():
-        img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
-        dL = (img - target) * inv_P
+        step_done.record(main_stream)              # everything enqueued so far (previous step incl. its exchange)
+        for v in range(VPS):
+            c = v % n_ctx
+            st = streams[c]
+            with torch.cuda.stream(st):
+                if n_ctx > 1 and v < n_ctx:
+                    st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
+                img = rasts[c].forward(params, cams[v], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled)
+                dL = (img - targets[v]) * inv_P
+                if n_ctx > 1 and v > 0:
+                    st.wait_event(bwd_done[(v - 1) % n_ctx])      # gradient rows are accumulated in view order
+                g = grads
+                if factorised:
+                    g = dict(grads); g["dcolor"] = fx.dcolor_local[v]
+                rasts[c].backward(dL, grads=g, accumulate=(v > 0), factorised_sh=factorised)
+                if n_ctx > 1:
+                    bwd_done[c].record(st)
+        if n_ctx > 1:
+            main_stream.wait_event(bwd_done[(VPS - 1) % n_ctx])
         if factorised:
-            rast.backward(dL, grads=grads, factorised_sh=True)
             fx.exchange(gbuf, rast, params["pos"], campos_all, deg, shn_tiled=tiled)
-        else:
-            rast.backward(dL, grads=grads)
-            if dist is not None:
-                dist.all_reduce(flat)
+        elif dist is not None:
+            dist.all_reduce(flat)
 
     for _ in range(args.warmup):
         step()
@@ -180,7 +214,7 @@ def main():
         for _ in range(args.profile_iters):
             img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
             dL = (img - target) * inv_P
-            rast.backward(dL, grads=grads)
+            rast.backward(dL, grads={k: v for k, v in grads.items() if k != "dcolor"})
             for k, v in rast.stage_timing().items():
                 acc.setdefault(k, []).append(v)
         rast.enable_timing(False)
@@ -198,7 +232,7 @@ def main():
         ab, p = algorithmic_bytes(n, V, T, Ppix, tiles, deg, bool(args.absgrad))
         total_bytes = sum(ab.values())
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
+        value = world * VPS * args.steps / elapsed
         # dominant kernel = the longest single-kernel stage
         single = {k: stage_ms[k] for k in ("render_bwd", "render_fwd", "preprocess_fwd", "preprocess_bwd", "duplicate") if k in stage_ms}
         roofline = None
@@ -222,15 +256,16 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, 1 view per GPU per step"
-                                   + ((", RCCL exchange of the gradient rows: " + args.exchange) if world > 1 else ""),
-                       "views_per_step": world, "absgrad": bool(args.absgrad), "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+            "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {VPS} view(s) per GPU per step"
+                                   + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
+                                   + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_view": total_bytes,
-                         "achieved_GBps_end_to_end": total_bytes / (ms_per_step * 1e-3) / 1e9 if world == 1 else None,
-                         "frac_of_hbm_peak_end_to_end": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
+                         "achieved_GBps_end_to_end": total_bytes * VPS / (ms_per_step * 1e-3) / 1e9 if world == 1 else None,
+                         "frac_of_hbm_peak_end_to_end": total_bytes * VPS / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
                          "sum_of_stage_ms": raster_ms, "stages": stage_table},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -239,7 +274,8 @@ def main():
             except Exception as e:      # the oracle is test infrastructure; its absence must not hide the GPU number
                 rec["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)
-    rast.close()
+    for r_ in rasts:
+        r_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -288,9 +288,6 @@ int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs
     HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.mean2d, s.conic_opacity,
                                    s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
     size_t e2 = tm.mark(); tm.span("render_bwd", e1, e2);
-    if (out->absgrad2d && opts->absgrad && opts->accumulate) {
-        g_last_error = "dvs_raster_backward: absgrad2d with accumulate is not supported"; return DVS_ERR_INVALID;
-    }
     HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
                                        s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
                                        out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor,

@@ -490,8 +490,16 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     }
 
     if (valid) {
-        if (out_absgrad2d) out_absgrad2d[i] = make_float2(r2.y, r2.z);
-        if (out_mean2d) out_mean2d[i] = make_float2(r0.x, r0.y);
+        if (out_absgrad2d) {
+            float2 a = make_float2(r2.y, r2.z);
+            if (ACCUM) { const float2 o = out_absgrad2d[i]; a.x += o.x; a.y += o.y; }
+            out_absgrad2d[i] = a;
+        }
+        if (out_mean2d) {
+            float2 mm = make_float2(r0.x, r0.y);
+            if (ACCUM) { const float2 o = out_mean2d[i]; mm.x += o.x; mm.y += o.y; }
+            out_mean2d[i] = mm;
+        }
         if (ACCUM) {
             g_opacity[i] += g_op;
             float4 o = reinterpret_cast<float4*>(g_rot)[i];

@@ -65,16 +65,17 @@ class FactorisedExchange:
     On MI355X's point-to-point xGMI links the exchange is bandwidth-bound, so this is ~2.5x less exposed time.
     """
 
-    def __init__(self, n, device, world):
-        self.n, self.world = n, world
-        self.dcolor_local = torch.zeros((n, 3), dtype=torch.float32, device=device)
-        self.dcolor_all = torch.zeros((world, n, 3), dtype=torch.float32, device=device)
+    def __init__(self, n, device, world, views_per_rank=1):
+        self.n, self.world, self.views_per_rank = n, world, views_per_rank
+        # dcolor_local[v] = colour gradient of this rank's v-th view; dcolor_all[r*V + v] after the all-gather
+        self.dcolor_local = torch.zeros((views_per_rank, n, 3), dtype=torch.float32, device=device)
+        self.dcolor_all = torch.zeros((world * views_per_rank, n, 3), dtype=torch.float32, device=device)
 
     def communicate(self, gbuf, group=None):
         """all-reduce(geometry slice) + all-gather(dcolor). Returns when both are complete on the current stream."""
         import torch.distributed as dist
         if self.world == 1:
-            self.dcolor_all[0].copy_(self.dcolor_local)
+            self.dcolor_all.copy_(self.dcolor_local)
             return
         work = dist.all_reduce(gbuf.flat_geom, op=dist.ReduceOp.SUM, group=group, async_op=True)
         try:

@@ -119,7 +119,7 @@ class Rasterizer:
             grads = {k: torch.empty_like(params[k]) for k in PARAM_KEYS}
             accumulate = False
         opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout)
-        if self._opts.absgrad and "absgrad2d" not in grads and not accumulate:
+        if self._opts.absgrad and "absgrad2d" not in grads:
             grads["absgrad2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
         if want_mean2d and "mean2d" not in grads:
             grads["mean2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)

@@ -11,21 +11,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(exchange, port):
+def _run(exchange, port, vps=1):
     env = dict(os.environ, DVS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--workload", "C2", "--no-cpu-baseline", "--profile-iters", "0", "--exchange", exchange]
+           "--workload", "C2", "--no-cpu-baseline", "--profile-iters", "0", "--exchange", exchange, "--views-per-step", str(vps)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)
 
 
-def test_factorised_exchange_equals_allreduce(gpu_device):
-    a = _run("allreduce", 29531)
-    f = _run("factorised", 29533)
-    assert a["n_gpus"] == 2 and f["n_gpus"] == 2 and a["config"]["views_per_step"] == 2
+@pytest.mark.parametrize("vps", [1, 2])
+def test_factorised_exchange_equals_allreduce(gpu_device, vps):
+    """vps = views per GPU per step: 1 = the north-star's "one view per GPU"; 2 exercises the two-context software pipeline,
+    gradient accumulation across the views of a step and the per-view dcolor slots of the factorised exchange."""
+    a = _run("allreduce", 29531 + 4 * vps, vps)
+    f = _run("factorised", 29533 + 4 * vps, vps)
+    assert a["n_gpus"] == 2 and f["n_gpus"] == 2 and a["config"]["views_per_step"] == 2 * vps
     for k, v in a["grad_l2_after_exchange"].items():
         assert v > 0
         assert abs(f["grad_l2_after_exchange"][k] - v) <= 1e-4 * v, (k, v, f["grad_l2_after_exchange"][k])
+
+
+def test_pipelined_views_accumulate_like_sequential(gpu_device):
+    """N=1: a step of 4 pipelined views leaves the same accumulated gradient as 4 sequential single-view steps would."""
+    import subprocess as sp
+    def run(vps):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "C2", "--no-cpu-baseline",
+               "--profile-iters", "0", "--views-per-step", str(vps)]
+        p = sp.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    g4 = run(4)["grad_l2_after_exchange"]
+    g1 = run(1)["grad_l2_after_exchange"]
+    assert g4["pos"] > 1.2 * g1["pos"]            # four different views accumulated, not one

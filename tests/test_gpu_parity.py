@@ -211,7 +211,7 @@ def test_factorised_sh_gradient(rast):
     torch.cuda.synchronize()
     m, worst = rel_close(gb.views["shN"].cpu().numpy(), 2 * ref["shN"].cpu().numpy(), 1e-4, 1e-5)
     assert m.all(), worst
-    assert fx.dcolor_all.shape == (1, n, 3)
+    assert fx.dcolor_all.shape == (1, n, 3) and fx.dcolor_local.shape == (1, n, 3)
 
 
 def test_tiled_shn_layout(rast):

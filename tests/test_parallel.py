@@ -43,7 +43,7 @@ def _worker_fact(rank, world, port, n, out):
     fx = FactorisedExchange(n, torch.device("cpu"), world)
     gb.flat_geom += (rank + 1) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
     gb.flat_sh.fill_(-1.0)                                   # must not be touched by the communication
-    fx.dcolor_local.copy_((rank + 1) * torch.ones((n, 3)) + torch.arange(n, dtype=torch.float32)[:, None])
+    fx.dcolor_local[0].copy_((rank + 1) * torch.ones((n, 3)) + torch.arange(n, dtype=torch.float32)[:, None])
     fx.communicate(gb)
     want = sum(range(1, world + 1)) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
     assert torch.allclose(gb.flat_geom, want, rtol=1e-6)
