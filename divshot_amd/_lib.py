@@ -80,7 +80,11 @@ _PROTOS = {
     "dvs_synth_target": (C.c_int, [C.POINTER(SceneSpec), C.c_int, C.c_void_p]),
     "dvs_make_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(Camera)]),
     "dvs_l1_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dvs_l1_loss_grad_w": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
     "dvs_l2_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
+    "dvs_ssim_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvs_ssim_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                    C.c_void_p, C.c_int]),
     "dvs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int]),
 }

@@ -75,12 +75,15 @@ static int grid_for(size_t count) {
 }
 
 extern "C" {
-int dvs_l1_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float* dL, float* loss_accum) {
+int dvs_l1_loss_grad_w(void* stream, const float* rgb, const float* target, size_t count, float weight, float* dL, float* loss_accum) {
     if (!rgb || !target || !dL) return DVS_ERR_INVALID;
     if (count == 0) return DVS_OK;
     hipLaunchKernelGGL(k_loss_grad<true>, dim3(grid_for(count)), dim3(TB), 0, (hipStream_t)stream, rgb, target, count,
-                       1.0f / (float)count, dL, loss_accum);
+                       weight / (float)count, dL, loss_accum);
     return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_l1_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float* dL, float* loss_accum) {
+    return dvs_l1_loss_grad_w(stream, rgb, target, count, 1.0f, dL, loss_accum);
 }
 int dvs_l2_loss_grad(void* stream, const float* rgb, const float* target, size_t count, float scale, float* dL, float* loss_accum) {
     if (!rgb || !target || !dL) return DVS_ERR_INVALID;

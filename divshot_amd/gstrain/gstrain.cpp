@@ -4,8 +4,8 @@
 // (plugin.cpp:89-111). The reference's implementation is closed source (README.md:46); this one keeps its call
 // sequence and ownership rules (scene allocated/freed by the plugin, config copied, bool from load_train_data) and
 // puts the MI355X rasterizer (include/dvs_raster.h) at the centre of train_step():
-//     sample camera -> dvs_raster_forward -> L1 loss gradient -> dvs_raster_backward -> fused Adam -> step++
-// Out of scope this round: SSIM term, densify/prune/opacity reset, COLMAP / image ingestion,
+//     sample camera -> dvs_raster_forward -> (1-w) L1 + w (1-SSIM) loss gradient -> dvs_raster_backward -> fused Adam -> step++
+// Out of scope this round: densify/prune/opacity reset, COLMAP / image ingestion,
 // mesh export. load_train_data accepts a synthetic-scene spec instead of a dataset path.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -59,7 +59,8 @@ struct GaussianTrainerScene::Impl {
     float* d_absgrad = nullptr;
     std::vector<dvs_camera> cams;
     std::vector<float*> d_targets;
-    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;
+    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0] = (1-w) L1, d_loss[1] = sum of the SSIM map
+    float* d_ssim_maps[3] = {nullptr, nullptr, nullptr};
     float last_loss = 0.f;
     int step = 0;
     uint64_t cam_rng = 88172645463325252ULL;
@@ -79,7 +80,7 @@ struct GaussianTrainerScene::Impl {
         }
         for (float* t : d_targets) (void)hipFree(t);
         d_targets.clear();
-        for (float** p : {&d_absgrad, &d_out, &d_dL, &d_loss}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (float** p : {&d_absgrad, &d_out, &d_dL, &d_loss, &d_ssim_maps[0], &d_ssim_maps[1], &d_ssim_maps[2]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         if (ctx) { dvs_destroy(ctx); ctx = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
@@ -169,7 +170,10 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     const size_t img = 3 * (size_t)W * H;
     HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
-    HIP_OR_THROW(hipMalloc((void**)&d_loss, sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_loss, 2 * sizeof(float)));
+    HIP_OR_THROW(hipMemset(d_loss, 0, 2 * sizeof(float)));
+    if (cfg.ssimWeight > 0.f)
+        for (int k = 0; k < 3; ++k) HIP_OR_THROW(hipMalloc((void**)&d_ssim_maps[k], img * sizeof(float)));
     dvs_opts opts{sh_max, cfg.mipAntiliased ? 1 : 0, 0, 0, DVS_SHN_TILED};
     const dvs_splats sp = splats();
     for (int c = 0; c < spec.n_cams; ++c) {
@@ -258,8 +262,16 @@ void GaussianTrainerScene::trainStep() {
     dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0, DVS_SHN_TILED};
     const dvs_splats sp = m.splats();
     DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, nullptr, nullptr));
-    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, sizeof(float), m.stream));
-    DVS_OR_THROW(dvs_l1_loss_grad(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, m.d_dL, m.d_loss));
+    // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25); its gradient goes straight into d_dL
+    const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
+    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, 2 * sizeof(float), m.stream));
+    DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, 1.f - w_ssim, m.d_dL, m.d_loss));
+    if (w_ssim > 0.f) {
+        DVS_OR_THROW(dvs_ssim_forward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
+                                      m.d_loss + 1));
+        DVS_OR_THROW(dvs_ssim_backward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
+                                       -w_ssim, m.d_dL, 1));
+    }
     dvs_splat_grads g{};
     g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
     g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = m.cfg.useAbsGrad ? m.d_absgrad : nullptr; g.mean2d = nullptr;
@@ -300,8 +312,11 @@ int GaussianTrainerScene::getCurrentIterations() const { return impl_->step; }
 float GaussianTrainerScene::getCurrentLoss() {
     Impl& m = *impl_;
     if (m.d_loss && m.stream) {
+        float h[2] = {0.f, 0.f};
         (void)hipStreamSynchronize(m.stream);
-        (void)hipMemcpy(&m.last_loss, m.d_loss, sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, m.d_loss, 2 * sizeof(float), hipMemcpyDeviceToHost);
+        const float w = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
+        m.last_loss = h[0] + (w > 0.f ? w * (1.f - h[1] / (3.f * (float)m.W * (float)m.H)) : 0.f);
     }
     return m.last_loss;
 }
