@@ -47,6 +47,11 @@ class SplatGrads(C.Structure):
                 ("scale", C.c_void_p), ("rot", C.c_void_p), ("absgrad2d", C.c_void_p), ("mean2d", C.c_void_p), ("dcolor", C.c_void_p)]
 
 
+class DensifyParams(C.Structure):
+    _fields_ = [("grad_threshold", C.c_float), ("scale_threshold", C.c_float), ("min_opacity", C.c_float), ("max_world_scale", C.c_float),
+                ("max_screen_radius", C.c_int32), ("cap_max", C.c_int32), ("seed", C.c_uint32), ("shn_layout", C.c_int32)]
+
+
 class SceneSpec(C.Structure):
     _fields_ = [("n", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sh_degree", C.c_int32),
                 ("n_cams", C.c_int32), ("seed", C.c_uint64), ("fov_x_deg", C.c_float), ("scale_log_offset", C.c_float)]
@@ -85,6 +90,11 @@ _PROTOS = {
     "dvs_ssim_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_ssim_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_void_p, C.c_int]),
+    "dvs_densify_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvs_densify_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DensifyParams),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvs_densify_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DensifyParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "dvs_reset_opacity": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "dvs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int]),
 }

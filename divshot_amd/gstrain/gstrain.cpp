@@ -5,7 +5,8 @@
 // sequence and ownership rules (scene allocated/freed by the plugin, config copied, bool from load_train_data) and
 // puts the MI355X rasterizer (include/dvs_raster.h) at the centre of train_step():
 //     sample camera -> dvs_raster_forward -> (1-w) L1 + w (1-SSIM) loss gradient -> dvs_raster_backward -> fused Adam -> step++
-// Out of scope this round: densify/prune/opacity reset, COLMAP / image ingestion,
+// -> every refineEvery steps clone / split / prune (ADC) and every resetAlphaEvery steps the opacity reset.
+// Out of scope this round: MCMC relocation, COLMAP / image ingestion,
 // mesh export. load_train_data accepts a synthetic-scene spec instead of a dataset path.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -56,7 +57,13 @@ struct GaussianTrainerScene::Impl {
     dvs_ctx* ctx = nullptr;
     int n = 0, W = 0, H = 0, sh_max = 3;
     float* d_param[6] = {}; float* d_grad[6] = {}; float* d_m[6] = {}; float* d_v[6] = {};
+    float* d_param2[6] = {}; float* d_m2[6] = {}; float* d_v2[6] = {};       // densification writes old -> new, then the sets swap
     float* d_absgrad = nullptr;
+    int cap = 0;                                                             // array capacity in splats (cfg.capMax)
+    float* d_grad_accum = nullptr; float* d_denom = nullptr; int* d_max_radii = nullptr;
+    uint8_t* d_action = nullptr; uint32_t* d_offsets = nullptr; uint32_t* d_dscratch = nullptr; uint64_t* d_newcount = nullptr;
+    float extent = 1.f;                                                      // scene extent (camera spread), sets the split/clone scale
+    dvs_fwd_state fwd{};
     std::vector<dvs_camera> cams;
     std::vector<float*> d_targets;
     float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0] = (1-w) L1, d_loss[1] = sum of the SSIM map
@@ -72,12 +79,10 @@ struct GaussianTrainerScene::Impl {
     void release() {
         if (device >= 0) (void)hipSetDevice(device);
         for (int g = 0; g < 6; ++g) {
-            if (d_param[g]) (void)hipFree(d_param[g]);
-            if (d_grad[g]) (void)hipFree(d_grad[g]);
-            if (d_m[g]) (void)hipFree(d_m[g]);
-            if (d_v[g]) (void)hipFree(d_v[g]);
-            d_param[g] = d_grad[g] = d_m[g] = d_v[g] = nullptr;
+            for (float** p : {&d_param[g], &d_grad[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         }
+        for (void** p : {(void**)&d_grad_accum, (void**)&d_denom, (void**)&d_max_radii, (void**)&d_action, (void**)&d_offsets,
+                         (void**)&d_dscratch, (void**)&d_newcount}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         for (float* t : d_targets) (void)hipFree(t);
         d_targets.clear();
         for (float** p : {&d_absgrad, &d_out, &d_dL, &d_loss, &d_ssim_maps[0], &d_ssim_maps[1], &d_ssim_maps[2]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -86,7 +91,8 @@ struct GaussianTrainerScene::Impl {
     }
     // floats of group g on the device: the 45 higher-order SH floats live in the DVS_SHN_TILED layout (48 per splat,
     // whole 64-splat tiles); parameters, gradients and Adam moments share it — the optimizer is element-wise.
-    size_t dev_floats(int g) const { return g == P_SHN ? (size_t)((n + 63) / 64) * 64 * 48 : (size_t)n * kWidth[g]; }
+    size_t dev_floats_for(int g, int count) const { return g == P_SHN ? (size_t)((count + 63) / 64) * 64 * 48 : (size_t)count * kWidth[g]; }
+    size_t dev_floats(int g) const { return dev_floats_for(g, n); }
     void upload(int g, const std::vector<float>& host_rows) {
         if (g != P_SHN) { HIP_OR_THROW(hipMemcpy(d_param[g], host_rows.data(), host_rows.size() * sizeof(float), hipMemcpyHostToDevice)); return; }
         float* tmp = nullptr;
@@ -96,22 +102,29 @@ struct GaussianTrainerScene::Impl {
         HIP_OR_THROW(hipStreamSynchronize(stream));
         (void)hipFree(tmp);
     }
-    void alloc_params(int count, const std::vector<float> init[6]) {
-        n = count;
+    void alloc_params(int count, int capacity, const std::vector<float> init[6]) {
+        n = count; cap = std::max(capacity, count);
         for (int g = 0; g < 6; ++g) {
-            const size_t bytes = dev_floats(g) * sizeof(float);
-            HIP_OR_THROW(hipMalloc((void**)&d_param[g], bytes ? bytes : 4));
-            HIP_OR_THROW(hipMalloc((void**)&d_grad[g], bytes ? bytes : 4));
-            HIP_OR_THROW(hipMalloc((void**)&d_m[g], bytes ? bytes : 4));
-            HIP_OR_THROW(hipMalloc((void**)&d_v[g], bytes ? bytes : 4));
-            HIP_OR_THROW(hipMemset(d_param[g], 0, bytes));
-            HIP_OR_THROW(hipMemset(d_grad[g], 0, bytes));      // pad lanes of the last tile are never written: keep them zero
-            HIP_OR_THROW(hipMemset(d_m[g], 0, bytes));
-            HIP_OR_THROW(hipMemset(d_v[g], 0, bytes));
+            const size_t bytes = dev_floats_for(g, cap) * sizeof(float);
+            for (float** p : {&d_param[g], &d_grad[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) {
+                HIP_OR_THROW(hipMalloc((void**)p, bytes ? bytes : 4));
+                HIP_OR_THROW(hipMemset(*p, 0, bytes));         // pad lanes of the last tile are never written: keep them zero
+            }
             upload(g, init[g]);
         }
-        HIP_OR_THROW(hipMalloc((void**)&d_absgrad, (size_t)n * 2 * sizeof(float) + 4));
+        HIP_OR_THROW(hipMalloc((void**)&d_absgrad, (size_t)cap * 2 * sizeof(float) + 4));
+        HIP_OR_THROW(hipMalloc((void**)&d_grad_accum, (size_t)cap * 4 + 4)); HIP_OR_THROW(hipMalloc((void**)&d_denom, (size_t)cap * 4 + 4));
+        HIP_OR_THROW(hipMalloc((void**)&d_max_radii, (size_t)cap * 4 + 4)); HIP_OR_THROW(hipMalloc((void**)&d_action, (size_t)cap + 4));
+        HIP_OR_THROW(hipMalloc((void**)&d_offsets, (size_t)cap * 4 + 4)); HIP_OR_THROW(hipMalloc((void**)&d_dscratch, ((size_t)cap / 256 + 8) * 4));
+        HIP_OR_THROW(hipMalloc((void**)&d_newcount, 8));
+        reset_stats();
     }
+    void reset_stats() {
+        HIP_OR_THROW(hipMemsetAsync(d_grad_accum, 0, (size_t)cap * 4, stream));
+        HIP_OR_THROW(hipMemsetAsync(d_denom, 0, (size_t)cap * 4, stream));
+        HIP_OR_THROW(hipMemsetAsync(d_max_radii, 0, (size_t)cap * 4, stream));
+    }
+    void densify(int it);
     dvs_splats splats() const {
         dvs_splats s{};
         s.pos = d_param[P_POS]; s.sh0 = d_param[P_SH0]; s.shN = d_param[P_SHN]; s.opacity = d_param[P_OPA];
@@ -163,10 +176,11 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     std::vector<float> gt[6];
     for (int g = 0; g < 6; ++g) gt[g].resize((size_t)spec.n * kWidth[g]);
     DVS_OR_THROW(dvs_synth_splats(&spec, gt[0].data(), gt[1].data(), gt[2].data(), gt[3].data(), gt[4].data(), gt[5].data()));
-    ctx = dvs_create(device, (size_t)std::max(spec.n, cfg.capMax > 0 ? std::min(cfg.capMax, spec.n * 2) : spec.n), W, H);
+    const int capacity = std::max(spec.n, cfg.capMax > 0 ? std::min(cfg.capMax, std::max(spec.n * 3, 4096)) : spec.n);
+    ctx = dvs_create(device, (size_t)capacity, W, H);
     if (!ctx) throw std::runtime_error(std::string("dvs_create: ") + dvs_last_error());
     // ground-truth views: render the generating scene once per camera
-    alloc_params(spec.n, gt);
+    alloc_params(spec.n, capacity, gt);
     const size_t img = 3 * (size_t)W * H;
     HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
@@ -185,13 +199,22 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
         cams.push_back(cam); d_targets.push_back(t);
     }
     HIP_OR_THROW(hipStreamSynchronize(stream));
+    {   // scene extent = 1.1 x the largest distance of a camera centre from their mean (the usual "cameras_extent"); a single
+        // camera or a tiny rig falls back to half the depth range of the synthetic slab
+        double mean[3] = {0, 0, 0};
+        for (auto& c : cams) for (int k = 0; k < 3; ++k) mean[k] += c.campos[k] / cams.size();
+        double far = 0;
+        for (auto& c : cams) { double d = 0; for (int k = 0; k < 3; ++k) d += (c.campos[k] - mean[k]) * (c.campos[k] - mean[k]); far = std::max(far, std::sqrt(d)); }
+        extent = far > 1e-3 ? (float)(1.1 * far) : 5.0f;
+    }
     // trainable initialisation = perturbed ground truth (or the checkpoint when --load_itr is given)
     std::vector<float> init[6];
     bool resumed = false;
     if (loadItr >= 0) {
         std::string err;
         resumed = gsply::read_ply(model_file(loadItr), init[0], init[1], init[2], init[3], init[4], init[5], &err) &&
-                  (int)init[3].size() == spec.n;
+                  !init[3].empty() && (int)init[3].size() <= cap;        // the count may differ from the spec after densification
+        if (resumed) n = (int)init[3].size();
         if (!resumed) logf_("could not resume from %s (%s): starting from the synthetic initialisation", model_file(loadItr).c_str(), err.c_str());
         else step = loadItr;
     }
@@ -210,6 +233,43 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     for (int g = 0; g < 6; ++g) upload(g, init[g]);
     if (cfg.verbose) logf_("synthetic scene: %d splats, %d cameras @ %dx%d, SH degree %d%s", spec.n, spec.n_cams, W, H, sh_max, resumed ? " (resumed)" : "");
     return true;
+}
+
+// clone / split / prune between two iterations (ADC; densifyStrategy 1 = MCMC in the reference is served by the same rule here)
+void GaussianTrainerScene::Impl::densify(int it) {
+    dvs_densify_params prm{};
+    prm.grad_threshold = cfg.growGrad2d;
+    prm.scale_threshold = 0.01f * extent;                       // percent_dense x extent
+    prm.min_opacity = cfg.min_opacity;
+    const bool after_reset = it > cfg.resetAlphaEvery;
+    prm.max_world_scale = after_reset ? 0.1f * extent : 0.f;
+    prm.max_screen_radius = after_reset ? 20 : 0;
+    prm.cap_max = cap; prm.seed = (uint32_t)it; prm.shn_layout = DVS_SHN_TILED;
+    uint64_t new_n = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        DVS_OR_THROW(dvs_densify_plan(stream, n, d_param[P_OPA], d_param[P_SCALE], d_grad_accum, d_denom, d_max_radii, &prm, d_action,
+                                      d_offsets, d_dscratch, d_newcount));
+        HIP_OR_THROW(hipMemcpyAsync(&new_n, d_newcount, 8, hipMemcpyDeviceToHost, stream));
+        HIP_OR_THROW(hipStreamSynchronize(stream));
+        if (new_n <= (uint64_t)cap) break;
+        prm.grad_threshold = 3.0e38f;                            // at the cap: prune only, no growth this round
+    }
+    if (new_n == 0 || new_n > (uint64_t)cap) { reset_stats(); return; }
+    for (int set = 0; set < 3; ++set) {
+        float** src = set == 0 ? d_param : (set == 1 ? d_m : d_v);
+        float** dst = set == 0 ? d_param2 : (set == 1 ? d_m2 : d_v2);
+        const float* s6[6] = {src[0], src[1], src[2], src[3], src[4], src[5]};
+        if (set > 0)
+            for (int g = 0; g < 6; ++g) HIP_OR_THROW(hipMemsetAsync(dst[g], 0, dev_floats_for(g, (int)new_n) * sizeof(float), stream));
+        else HIP_OR_THROW(hipMemsetAsync(dst[P_SHN], 0, dev_floats_for(P_SHN, (int)new_n) * sizeof(float), stream));   // tile pads
+        DVS_OR_THROW(dvs_densify_apply(stream, n, d_action, d_offsets, &prm, set == 0 ? 0 : 1, s6, dst, (int)new_n));
+        for (int g = 0; g < 6; ++g) std::swap(src[g], dst[g]);
+    }
+    if (cfg.verbose) logf_("densify @%d: %d -> %llu splats", it, n, (unsigned long long)new_n);
+    n = (int)new_n;
+    HIP_OR_THROW(hipMemsetAsync(d_grad[P_SHN], 0, dev_floats_for(P_SHN, cap) * sizeof(float), stream));   // pad lanes of the new last tile
+    reset_stats();
+    host_valid = false;
 }
 
 GaussianTrainerScene::GaussianTrainerScene(const GaussianTrainConfig& cfg, int loadItr) : impl_(new Impl()) {
@@ -261,7 +321,7 @@ void GaussianTrainerScene::trainStep() {
     const int deg = m.cfg.progressiveTrain ? std::min(m.sh_max, m.step / 1000) : m.sh_max;   // SH bands unlocked every 1000 steps
     dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0, DVS_SHN_TILED};
     const dvs_splats sp = m.splats();
-    DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, nullptr, nullptr));
+    DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, &m.fwd, nullptr));
     // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25); its gradient goes straight into d_dL
     const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
     HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, 2 * sizeof(float), m.stream));
@@ -276,6 +336,9 @@ void GaussianTrainerScene::trainStep() {
     g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
     g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = m.cfg.useAbsGrad ? m.d_absgrad : nullptr; g.mean2d = nullptr;
     DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
+    const bool refining = m.cfg.useAbsGrad && it < m.cfg.refineStopIter;
+    if (refining)      // densification statistics of this view
+        DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, m.d_absgrad, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
     // Adam, per-group learning rates (names gs_train.cpp:52-57; position lr decays exponentially init -> final)
     const float t = std::min(1.0f, (float)m.step / (float)std::max(1, m.cfg.numIters));
     const float lr_pos = std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
@@ -283,6 +346,9 @@ void GaussianTrainerScene::trainStep() {
     for (int k = 0; k < 6; ++k)
         DVS_OR_THROW(dvs_adam_step(m.stream, m.d_param[k], m.d_grad[k], m.d_m[k], m.d_v[k], m.dev_floats(k), lr[k], 0.9f, 0.999f,
                                    1e-15f, it));
+    if (refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0) m.densify(it);
+    if (refining && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0)
+        DVS_OR_THROW(dvs_reset_opacity(m.stream, m.n, m.d_param[P_OPA], 0.01f, m.d_m[P_OPA], m.d_v[P_OPA]));
     if (m.cfg.verbose && (m.step % 100 == 0))          // same line the editor logs (application/editor/source/editor.cpp:1554)
         logf_("Iteraions %d, loss : %f", m.step, (double)getCurrentLoss());
     m.step = it;

@@ -39,6 +39,47 @@ int dvs_ssim_backward(void* stream, const float* img, const float* target, int w
 int dvs_adam_step(void* stream, float* param, const float* grad, float* m, float* v, size_t count, float lr, float beta1,
                   float beta2, float eps, int step);
 
+/* ---- adaptive density control: clone / split / prune, the "ADC" strategy of --densifyStrategy -------------
+ * (flags application/diverseshot-cli/source/main.cpp:20,29,46-65: growGrad2d 2e-4, warmupLength 500, refineEvery 100, resetAlphaEvery
+ * 3000, refineStopIter 15000, minOpacity 0.005, capMax gs_train.cpp:89). The reference's own densifier is in the closed plugin; this
+ * is the public ADC rule it names, operating in place on HBM-resident arrays with no host round trip except the new count.
+ *
+ * Per refinement interval:
+ *   dvs_densify_accumulate after every backward: for visible splats  grad_accum += |g| (g = abs-grad of the 2D mean in NDC units:
+ *                          pixel-unit gradient x 0.5*(W,H)),  denom += 1,  max_radii = max(max_radii, radius).
+ *   dvs_densify_plan       action per splat from avg = grad_accum/denom:   PRUNE  sigmoid(opacity) < min_opacity, or world/screen size
+ *                          above the limits;  SPLIT  avg >= grad_threshold and max exp(scale) > scale_threshold (replaced by 2
+ *                          samples, scale / 1.6);  CLONE  avg >= grad_threshold otherwise (kept + 1 copy);  KEEP.
+ *                          Writes action[n], the exclusive scan of the output counts offsets[n] and the new count (device + pinned host
+ *                          copy is the caller's business). Growth is cut off deterministically (by splat index) at cap_max.
+ *   dvs_densify_apply      scatters ONE attribute set old -> new at the planned offsets. mode 0 = parameters (split samples drawn
+ *                          from the splat's own Gaussian with a counter-based hash RNG), mode 1 = optimizer moments (kept rows copied,
+ *                          rows of new splats zero). shN arrays may be in either layout (shn_layout).
+ */
+enum { DVS_DENSIFY_KEEP = 0, DVS_DENSIFY_CLONE = 1, DVS_DENSIFY_SPLIT = 2, DVS_DENSIFY_PRUNE = 3 };
+typedef struct dvs_densify_params {
+    float grad_threshold;      /* growGrad2d */
+    float scale_threshold;     /* world units: percent_dense * scene extent */
+    float min_opacity;         /* prune below (activated opacity) */
+    float max_world_scale;     /* prune if max exp(scale) exceeds it; 0 = off */
+    int32_t max_screen_radius; /* prune if max_radii exceeds it; 0 = off */
+    int32_t cap_max;           /* hard cap on the new count */
+    uint32_t seed;             /* RNG stream for split samples (use the step number) */
+    int32_t shn_layout;        /* DVS_SHN_ROWS / DVS_SHN_TILED for the shN arrays passed to dvs_densify_apply */
+} dvs_densify_params;
+
+int dvs_densify_accumulate(void* stream, int n, const int32_t* radii, const float* absgrad2d, int width, int height,
+                           float* grad_accum, float* denom, int32_t* max_radii);
+/* scratch: at least (n/256 + 2) uint32; new_count: DEVICE uint64. */
+int dvs_densify_plan(void* stream, int n, const float* opacity, const float* scale, const float* grad_accum, const float* denom,
+                     const int32_t* max_radii, const dvs_densify_params* prm, uint8_t* action, uint32_t* offsets, uint32_t* scratch,
+                     uint64_t* new_count);
+/* src/dst: six DEVICE arrays in A0 order (pos, sh0, shN, opacity, scale, rot); dst sized for the new count. */
+int dvs_densify_apply(void* stream, int n, const uint8_t* action, const uint32_t* offsets, const dvs_densify_params* prm, int mode,
+                      const float* const src[6], float* const dst[6], int new_n);
+/* opacity reset (--resetAlphaEvery): opacity = min(opacity, logit(max_opacity)); zeroes the matching Adam moments if given. */
+int dvs_reset_opacity(void* stream, int n, float* opacity, float max_opacity, float* adam_m, float* adam_v);
+
 #ifdef __cplusplus
 }
 #endif

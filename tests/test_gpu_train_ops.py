@@ -82,3 +82,85 @@ def test_l1_and_adam(gpu_device):
         m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
         p = p - 1e-2 * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
     np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_densify_plan_and_apply(gpu_device, tiled):
+    """ADC clone / split / prune against a numpy restatement of the rule."""
+    import ctypes as C
+    import torch
+    from divshot_amd._lib import lib, DensifyParams, check
+    from divshot_amd.raster import shn_rows_to_tiled_np, shn_tiled_to_rows_np, tiled_floats
+    rng = np.random.default_rng(2)
+    n = 10_007
+    A = {"pos": rng.normal(size=(n, 3)), "sh0": rng.normal(size=(n, 3)), "shN": rng.normal(size=(n, 15, 3)),
+         "opacity": rng.normal(0, 3, size=(n,)), "scale": rng.normal(-3, 1, size=(n, 3)), "rot": rng.normal(size=(n, 4))}
+    A = {k: v.astype(np.float32) for k, v in A.items()}
+    radii = rng.integers(0, 40, n).astype(np.int32)
+    absg = np.abs(rng.normal(0, 3e-7, (n, 2))).astype(np.float32)
+    W, H = 640, 360
+    dev = gpu_device
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = lambda a: torch.tensor(a, device=dev)
+    ga, de, mr = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+    radii_d, absg_d = t(radii), t(absg)          # keep the device tensors alive while their raw pointers are in use
+    for _ in range(3):
+        check(lib.dvs_densify_accumulate(st, n, radii_d.data_ptr(), absg_d.data_ptr(), W, H, ga.data_ptr(), de.data_ptr(), mr.data_ptr()))
+    vis = radii > 0
+    g_ref = np.where(vis, 3 * np.hypot(absg[:, 0] * W / 2, absg[:, 1] * H / 2), 0)
+    np.testing.assert_allclose(ga.cpu().numpy(), g_ref, rtol=1e-5)
+    assert np.array_equal(de.cpu().numpy(), np.where(vis, 3.0, 0.0)) and np.array_equal(mr.cpu().numpy(), np.where(vis, radii, 0))
+    prm = DensifyParams(grad_threshold=2e-4, scale_threshold=0.05, min_opacity=0.005, max_world_scale=0.0, max_screen_radius=0,
+                        cap_max=10 ** 9, seed=77, shn_layout=1 if tiled else 0)
+    action = torch.zeros(n, dtype=torch.uint8, device=dev); offs = torch.zeros(n, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(n // 256 + 4, dtype=torch.int32, device=dev); total = torch.zeros(1, dtype=torch.int64, device=dev)
+    op_d, sc_d = t(A["opacity"]), t(A["scale"])
+    check(lib.dvs_densify_plan(st, n, op_d.data_ptr(), sc_d.data_ptr(), ga.data_ptr(), de.data_ptr(), mr.data_ptr(), C.byref(prm),
+                               action.data_ptr(), offs.data_ptr(), scratch.data_ptr(), total.data_ptr()))
+    torch.cuda.synchronize()
+    sig = 1 / (1 + np.exp(-A["opacity"].astype(np.float64)))
+    smax = np.exp(A["scale"].max(1).astype(np.float64))
+    avg = np.where(vis, g_ref / 3.0, 0.0)
+    want = np.where(sig < 0.005, 3, np.where(avg >= 2e-4, np.where(smax > 0.05, 2, 1), 0))
+    got = action.cpu().numpy()
+    borderline = (np.abs(sig - 0.005) < 1e-6) | (np.abs(avg - 2e-4) < 1e-9) | (np.abs(smax - 0.05) < 1e-6)
+    assert np.array_equal(got[~borderline], want[~borderline])
+    cnt = np.where(got == 3, 0, np.where(got == 0, 1, 2))
+    assert np.array_equal(offs.cpu().numpy().view(np.uint32), np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.uint32))
+    new_n = int(total.item())
+    assert new_n == cnt.sum() and {0, 1, 2, 3} <= set(got.tolist())
+    shn_np = shn_rows_to_tiled_np(A["shN"]) if tiled else A["shN"].reshape(-1)
+    src = [t(A["pos"]), t(A["sh0"]), t(shn_np), op_d, sc_d, t(A["rot"])]
+    shn_new = tiled_floats(new_n) if tiled else new_n * 45
+    for mode in (0, 1):
+        dst = [torch.full((new_n * 3,), 9.0, device=dev), torch.full((new_n * 3,), 9.0, device=dev), torch.zeros(shn_new, device=dev),
+               torch.full((new_n,), 9.0, device=dev), torch.full((new_n * 3,), 9.0, device=dev), torch.full((new_n * 4,), 9.0, device=dev)]
+        sp = (C.c_void_p * 6)(*[x.data_ptr() for x in src]); dp = (C.c_void_p * 6)(*[x.data_ptr() for x in dst])
+        check(lib.dvs_densify_apply(st, n, action.data_ptr(), offs.data_ptr(), C.byref(prm), mode, sp, dp, new_n))
+        torch.cuda.synchronize()
+        pos = dst[0].cpu().numpy().reshape(new_n, 3); sc = dst[4].cpu().numpy().reshape(new_n, 3)
+        op = dst[3].cpu().numpy(); rot = dst[5].cpu().numpy().reshape(new_n, 4)
+        shn = shn_tiled_to_rows_np(dst[2].cpu().numpy(), new_n) if tiled else dst[2].cpu().numpy().reshape(new_n, 15, 3)
+        o = offs.cpu().numpy().view(np.uint32).astype(np.int64)
+        keep, clone, split = np.where(got == 0)[0], np.where(got == 1)[0], np.where(got == 2)[0]
+        assert not (pos == 9.0).any()                                         # every output row was written
+        if mode == 0:
+            for idx, slots in ((keep, (0,)), (clone, (0, 1))):
+                for c in slots:
+                    assert np.array_equal(pos[o[idx] + c], A["pos"][idx]) and np.array_equal(shn[o[idx] + c], A["shN"][idx])
+                    assert np.array_equal(op[o[idx] + c], A["opacity"][idx]) and np.array_equal(sc[o[idx] + c], A["scale"][idx])
+            for c in (0, 1):
+                np.testing.assert_allclose(sc[o[split] + c], A["scale"][split] - np.log(1.6), rtol=1e-6, atol=1e-6)
+                assert np.array_equal(rot[o[split] + c], A["rot"][split]) and np.array_equal(shn[o[split] + c], A["shN"][split])
+                d = np.abs(pos[o[split] + c] - A["pos"][split]).max(1)
+                assert (d <= 6.0 * np.exp(A["scale"][split].max(1)) + 1e-6).all() and (d > 0).mean() > 0.99
+            assert not np.array_equal(pos[o[split]], pos[o[split] + 1])       # the two children are different samples
+        else:
+            assert np.array_equal(pos[o[keep]], A["pos"][keep]) and np.array_equal(pos[o[clone]], A["pos"][clone])
+            assert not pos[o[clone] + 1].any() and not pos[o[split]].any() and not pos[o[split] + 1].any() and not shn[o[split]].any()
+    # opacity reset
+    m, v = torch.ones(n, device=dev), torch.ones(n, device=dev)
+    check(lib.dvs_reset_opacity(st, n, op_d.data_ptr(), 0.01, m.data_ptr(), v.data_ptr()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(op_d.cpu().numpy(), np.minimum(A["opacity"], np.log(0.01 / 0.99)), rtol=1e-6)
+    assert not m.any() and not v.any()

@@ -87,3 +87,28 @@ def test_cli_trains_synthetic_scene(tmp_path):
     assert subprocess.run([DRIVER, "--bogus", "1"], capture_output=True).returncode != 0
     p3 = subprocess.run([DRIVER, "--inputPath", "/nonexistent/dataset"], capture_output=True, text=True)
     assert p3.returncode != 0 and "load data failed" in p3.stdout
+
+
+@pytest.mark.gpu
+def test_cli_densify_prune_reset(tmp_path):
+    """ADC active (SURVEY.md §8(f) row 1 / BASELINE config C5's "densify/prune active"): the splat count changes between
+    iterations, training keeps going, the checkpoint has the new count and can be resumed."""
+    out = str(tmp_path / "m" / "iteration")
+    cmd = [DRIVER, "--inputPath", "synthetic:N=30000,W=320,H=240,cams=6,sh=2,seed=5", "--maxIteration", "1000", "--outputPath", out,
+           "--warmupLength", "100", "--refineEvery", "100", "--resetAlphaEvery", "300", "--refineStopIter", "450", "--growGrad2d", "0.00005"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    steps = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"densify @(\d+): (\d+) -> (\d+) splats", p.stderr)]
+    assert len(steps) == 3 and steps[0][0] == 200, p.stderr[-1500:]        # refinement at 200, 300, 400 (stops before 450)
+    assert any(b != a for _, a, b in steps)                      # the count really changes
+    assert all(b <= 90000 for _, _, b in steps)                  # capacity = 3 x the initial count here
+    losses = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+|nan|inf)", p.stderr)]
+    # the opacity reset at 300 makes the loss jump (expected); by the end training has recovered
+    assert len(losses) >= 9 and all(np.isfinite(losses)) and max(losses) > 0.3 and losses[-1] < 0.5 * losses[0]
+    final_n = steps[-1][2]
+    ply = out + "_1000.ply"
+    assert os.path.getsize(ply) > final_n * 236 and os.path.getsize(ply) < final_n * 236 + 4096
+    head = open(ply, "rb").read(400).decode(errors="ignore")
+    assert f"element vertex {final_n}" in head
+    p2 = subprocess.run(cmd[:cmd.index("1000")] + ["1020"] + cmd[cmd.index("1000") + 1:] + ["--load_itr", "1000"], capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0 and "(resumed)" in p2.stderr, p2.stderr[-1500:]
