@@ -110,6 +110,8 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float ty = dvs_xform(cam.view, px, py, pz, 1);
         const float tz = dvs_xform(cam.view, px, py, pz, 2);
         if (!(tz > DVS_NEAR)) break;
+        // a NaN log-scale or opacity logit culls the splat (the clamps inside dvs_exp_det would otherwise turn it into a number)
+        if (!(in_s0 == in_s0) || !(in_s1 == in_s1) || !(in_s2 == in_s2) || !(in_op == in_op)) break;
         const float hx = dvs_xform(cam.proj, px, py, pz, 0);
         const float hy = dvs_xform(cam.proj, px, py, pz, 1);
         const float hw = dvs_xform(cam.proj, px, py, pz, 3);

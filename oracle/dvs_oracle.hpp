@@ -193,6 +193,10 @@ template <class T> void preprocess_forward(State<T>& S) {
         const T ty = xform_x<T>(cam.view, px, py, pz, 1);
         const T tz = xform_x<T>(cam.view, px, py, pz, 2);
         if (!(tz > T(kNear))) continue;                                   // near cull (NaN-safe)
+        {   // a NaN log-scale or opacity logit culls the splat (the clamps inside det_exp would otherwise turn it into a number)
+            const T l0 = S.scale[3 * i], l1 = S.scale[3 * i + 1], l2 = S.scale[3 * i + 2], lo = S.opacity[i];
+            if (!(l0 == l0) || !(l1 == l1) || !(l2 == l2) || !(lo == lo)) continue;
+        }
         const T hx = xform_x<T>(cam.proj, px, py, pz, 0);
         const T hy = xform_x<T>(cam.proj, px, py, pz, 1);
         const T hw = xform_x<T>(cam.proj, px, py, pz, 3);

@@ -354,3 +354,48 @@ def test_sort_pairs(rast):
         torch.cuda.synchronize()
         order = np.argsort(keys, kind="stable")
         np.testing.assert_array_equal(v_d.cpu().numpy().view(np.uint32), vals[order])
+
+
+def test_error_paths_and_nan_inputs(gpu_device):
+    """Status codes instead of crashes or silent fallbacks; NaN / inf parameters cull the splat and poison nothing else."""
+    import ctypes as C
+    import torch
+    from divshot_amd._lib import lib, Splats, Opts, SplatGrads
+    from divshot_amd.raster import Rasterizer, params_to_device
+    r = Rasterizer(0, max_splats=1000, max_w=128, max_h=96)
+    spec = dv.make_spec(2000, 128, 96, sh_degree=3)
+    P = dv.synth_splats(spec)
+    cam = dv.synth_camera(spec, 0)
+    Pd = params_to_device(P, r.tdev)
+    with pytest.raises(dv.DvsError, match="capacity"):
+        r.forward(Pd, cam)                                   # n = 2000 > max_splats = 1000
+    small = {k: v[:500].contiguous() for k, v in Pd.items()}
+    with pytest.raises(dv.DvsError, match="sh_degree"):
+        r.forward(small, cam, sh_degree=4)
+    big = dv.synth_camera(dv.make_spec(10, 4096, 96), 0)
+    with pytest.raises(dv.DvsError, match="capacity"):
+        r.forward(small, big)                                # image wider than max_w
+    # backward without a forward on this context
+    sp = Splats(*[small[k].data_ptr() for k in ("pos", "sh0", "shN", "opacity", "scale", "rot")], 500, 0)
+    g = {k: torch.empty_like(v) for k, v in small.items()}
+    sg = SplatGrads(*[g[k].data_ptr() for k in ("pos", "sh0", "shN", "opacity", "scale", "rot")], None, None, None)
+    dL = torch.zeros((3, 96, 128), device=r.tdev)
+    opts = Opts(3, 0, 0, 0, 0)
+    assert lib.dvs_raster_backward(r.ctx, None, C.byref(sp), C.byref(cam), C.byref(opts), dL.data_ptr(), C.byref(sg)) == 4   # DVS_ERR_STATE
+    assert b"forward" in lib.dvs_last_error()
+    # NaN / inf parameters
+    bad = {k: v.clone() for k, v in small.items()}
+    bad["pos"][0, 0] = float("nan"); bad["scale"][1, 1] = float("inf"); bad["rot"][2] = float("nan"); bad["opacity"][3] = float("nan")
+    bad["scale"][4] = -float("inf")
+    img = r.forward(bad, cam, sh_degree=3)
+    torch.cuda.synchronize()
+    s = r.saved()
+    assert (s["radii"][[0, 2, 3]] == 0).all() and s["radii"][4] >= 0 and np.isfinite(s["conic_opacity"]).all()
+    assert torch.isfinite(img).all()
+    ref = r.forward({k: v[5:].contiguous() for k, v in small.items()}, cam, sh_degree=3).clone()
+    img2 = r.forward({k: v[5:].contiguous() for k, v in bad.items()}, cam, sh_degree=3)
+    assert torch.equal(ref, img2)
+    grads = r.backward(torch.ones_like(img2))
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    r.close()
