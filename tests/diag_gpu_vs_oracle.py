@@ -1,7 +1,8 @@
-"""Diagnostic dump: per-stage GPU-vs-oracle differences for one config (development aid)."""
+"""Diagnostic dump: per-stage GPU-vs-oracle differences for one config (development aid; lives under tests/ because it
+uses the CPU oracle). usage: python tests/diag_gpu_vs_oracle.py N W H DEG [aa]   (env SEED, SOFF)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import divshot_amd as dv
 from divshot_amd.raster import Rasterizer, params_to_device
