@@ -52,6 +52,11 @@ class DensifyParams(C.Structure):
                 ("max_screen_radius", C.c_int32), ("cap_max", C.c_int32), ("seed", C.c_uint32), ("shn_layout", C.c_int32)]
 
 
+class AdamGroup(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("count", C.c_uint64),
+                ("lr", C.c_float), ("width", C.c_int32), ("layout", C.c_int32), ("active_chunks", C.c_int32)]
+
+
 class SceneSpec(C.Structure):
     _fields_ = [("n", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sh_degree", C.c_int32),
                 ("n_cams", C.c_int32), ("seed", C.c_uint64), ("fov_x_deg", C.c_float), ("scale_log_offset", C.c_float)]
@@ -97,6 +102,8 @@ _PROTOS = {
     "dvs_reset_opacity": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "dvs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int]),
+    "dvs_adam_step_groups": (C.c_int, [C.c_void_p, C.POINTER(AdamGroup), C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                                       C.c_int32]),
 }
 for _name, (_res, _args) in _PROTOS.items():
     _f = getattr(lib, _name)          # AttributeError here = the .so does not export a declared symbol

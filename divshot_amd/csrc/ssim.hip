@@ -8,6 +8,7 @@
 // backward (x = rendered image, y = target, constant):
 //   dL/dx = G*(dm_dmu1) + 2 x G*(dm_ds1) + y G*(dm_ds12)     with the three per-pixel maps produced by the forward.
 #include <hip/hip_runtime.h>
+#include <climits>
 #include "../../include/dvs_train.h"
 #include "../../include/dvs_raster.h"
 
@@ -29,12 +30,31 @@ __device__ __forceinline__ float block_sum256(float v, float* tmp) {
     return tmp[0] + tmp[1] + tmp[2] + tmp[3];
 }
 
-// load a 26x26 patch of plane `src` (zero outside the image) into LDS
-__device__ __forceinline__ void load_patch(const float* __restrict__ src, int W, int H, int x0, int y0, float (*dst)[SP]) {
-    for (int e = threadIdx.x; e < SP * SP; e += ST * ST) {
-        const int py = e / SP, px = e % SP;
+// load the 26x26 patches of NP planes (zero outside the image) into LDS. All 3*NP global loads are issued before the first
+// LDS write (clamped address + select instead of a branch): with a branch per element the loads serialise and the kernel
+// is bound by 3*NP dependent HBM round trips per workgroup.
+template <int NP>
+__device__ __forceinline__ void load_patches(const float* const (&src)[NP], int W, int H, int x0, int y0, float (*const (&dst)[NP])[SP]) {
+    constexpr int IT = (SP * SP + ST * ST - 1) / (ST * ST);
+    float r[NP][IT];
+    int at[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int e = threadIdx.x + it * ST * ST;
+        const int py = e / SP, px = e - py * SP;
         const int gx = x0 + px - HALO, gy = y0 + py - HALO;
-        dst[py][px] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.f;
+        const bool inb = e < SP * SP && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const size_t idx = inb ? (size_t)gy * W + gx : 0;
+        at[it] = e < SP * SP ? (inb ? e : ~e) : INT_MIN;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) r[p][it] = src[p][idx];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (at[it] == INT_MIN) continue;
+        const int e = at[it] >= 0 ? at[it] : ~at[it];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) (&dst[p][0][0])[e] = at[it] >= 0 ? r[p][it] : 0.f;
     }
 }
 
@@ -47,8 +67,11 @@ k_ssim_fwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
     const int ch = blockIdx.z;
     const size_t plane = (size_t)ch * W * H;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-    load_patch(img + plane, W, H, x0, y0, sx);
-    load_patch(tgt + plane, W, H, x0, y0, sy);
+    {
+        const float* const src[2] = {img + plane, tgt + plane};
+        float (*const dst[2])[SP] = {sx, sy};
+        load_patches<2>(src, W, H, x0, y0, dst);
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < SP * ST; e += ST * ST) {
         const int py = e / ST, px = e % ST;
@@ -74,15 +97,17 @@ k_ssim_fwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
         const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
         const float s1 = exx - mu1s, s2 = eyy - mu2s, s12 = exy - mu12;
         const float A = mu1s + mu2s + SSIM_C1, B = s1 + s2 + SSIM_C2, Cn = 2.f * mu12 + SSIM_C1, Dn = 2.f * s12 + SSIM_C2;
-        const float m = (Cn * Dn) / (A * B);
+        const float iAB = 1.f / (A * B), iA = iAB * B, iB = iAB * A;       // one division per pixel
+        const float m = Cn * Dn * iAB;
         local = m;
         const size_t o = plane + (size_t)gy * W + gx;
-        dm_dmu1[o] = (mu2 * 2.f * Dn) / (A * B) - (mu2 * 2.f * Cn) / (A * B) - (mu1 * 2.f * Cn * Dn) / (A * A * B) + (mu1 * 2.f * Cn * Dn) / (A * B * B);
-        dm_ds1[o] = -(Cn * Dn) / (A * B * B);
-        dm_ds12[o] = (2.f * Cn) / (A * B);
+        dm_dmu1[o] = 2.f * iAB * (mu2 * (Dn - Cn) + mu1 * Cn * Dn * (iB - iA));
+        dm_ds1[o] = -m * iB;
+        dm_ds12[o] = 2.f * Cn * iAB;
     }
     const float s = block_sum256(local, tmp);
-    if (threadIdx.x == 0 && ssim_sum) atomicAdd(ssim_sum, s);
+    // one atomic per workgroup, spread over DVS_SSIM_SLOTS addresses (30k same-address atomics serialise for ~0.3 ms)
+    if (threadIdx.x == 0 && ssim_sum) atomicAdd(ssim_sum + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (DVS_SSIM_SLOTS - 1)), s);
 }
 
 template <bool ACCUM>
@@ -94,9 +119,11 @@ k_ssim_bwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
     const int ch = blockIdx.z;
     const size_t plane = (size_t)ch * W * H;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-    load_patch(dm_dmu1 + plane, W, H, x0, y0, sa);
-    load_patch(dm_ds1 + plane, W, H, x0, y0, sb);
-    load_patch(dm_ds12 + plane, W, H, x0, y0, sc);
+    {
+        const float* const src[3] = {dm_dmu1 + plane, dm_ds1 + plane, dm_ds12 + plane};
+        float (*const dst[3])[SP] = {sa, sb, sc};
+        load_patches<3>(src, W, H, x0, y0, dst);
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < SP * ST; e += ST * ST) {
         const int py = e / ST, px = e % ST;

@@ -67,6 +67,84 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
         }
 }
 
+// ---- grouped Adam: one launch for every parameter group --------------------------------------------------------------------
+struct AdamGroupDev {
+    float* p; const float* g; float* m; float* v;
+    unsigned long long nvec;        // float4 items this group contributes (after the active-chunk compaction)
+    unsigned long long tail0, tail1;// scalar tail [tail0, tail1)
+    float lr; int width; int tiled; int active_vec;      // active_vec: float4 per 64-splat tile that are processed (tiled only)
+    unsigned block0;                // first workgroup of this group
+};
+struct AdamGroupsDev { AdamGroupDev g[DVS_ADAM_MAX_GROUPS]; int n; };
+
+#define ADAM_VPT 2                  // float4 per thread: two independent load batches in flight
+
+__device__ __forceinline__ bool adam_vis(const int* __restrict__ vis, int n_splats, const AdamGroupDev& G, unsigned long long e) {
+    if (!vis) return true;
+    unsigned long long splat;
+    if (G.tiled) splat = (e / DVS_SHN_TILE_FLOATS) * 64ull + ((e % DVS_SHN_TILE_FLOATS) >> 2 & 63ull);
+    else splat = e / (unsigned)G.width;
+    return splat < (unsigned long long)n_splats && vis[splat] > 0;
+}
+
+__global__ void __launch_bounds__(TB)
+k_adam_groups(const AdamGroupsDev G, const int* __restrict__ vis, int n_splats, float b1, float b2, float eps, float bc1, float bc2) {
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < DVS_ADAM_MAX_GROUPS; ++k) gi += (k < G.n && blockIdx.x >= G.g[k].block0) ? 1 : 0;
+    const AdamGroupDev& A = G.g[gi];
+    const unsigned long long base = (unsigned long long)(blockIdx.x - A.block0) * (TB * ADAM_VPT) + threadIdx.x;
+    unsigned long long idx[ADAM_VPT];
+    bool on[ADAM_VPT];
+    float4 pp[ADAM_VPT], mm[ADAM_VPT], vv[ADAM_VPT], gg[ADAM_VPT];
+#pragma unroll
+    for (int u = 0; u < ADAM_VPT; ++u) {
+        const unsigned long long j = base + (unsigned long long)u * TB;
+        on[u] = j < A.nvec;
+        unsigned long long i = j;
+        if (A.tiled && A.active_vec != DVS_SHN_TILE_FLOATS / 4) {
+            const unsigned long long tile = j / (unsigned)A.active_vec;
+            i = tile * (DVS_SHN_TILE_FLOATS / 4) + (j - tile * (unsigned)A.active_vec);
+        }
+        idx[u] = on[u] ? i : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < ADAM_VPT; ++u)
+        if (on[u]) {
+            gg[u] = reinterpret_cast<const float4*>(A.g)[idx[u]];
+            pp[u] = reinterpret_cast<float4*>(A.p)[idx[u]];
+            mm[u] = reinterpret_cast<float4*>(A.m)[idx[u]];
+            vv[u] = reinterpret_cast<float4*>(A.v)[idx[u]];
+        }
+#pragma unroll
+    for (int u = 0; u < ADAM_VPT; ++u)
+        if (on[u]) {
+            const unsigned long long e0 = idx[u] << 2;
+            bool any = false;
+#define DVS_ADAM1V(c, k)                                                                         \
+            if (adam_vis(vis, n_splats, A, e0 + k)) {                                                      \
+                mm[u].c = b1 * mm[u].c + (1.f - b1) * gg[u].c;                                   \
+                vv[u].c = b2 * vv[u].c + (1.f - b2) * gg[u].c * gg[u].c;                         \
+                pp[u].c -= A.lr * (mm[u].c * bc1) / (sqrtf(vv[u].c * bc2) + eps);                \
+                any = true;                                                                      \
+            }
+            DVS_ADAM1V(x, 0) DVS_ADAM1V(y, 1) DVS_ADAM1V(z, 2) DVS_ADAM1V(w, 3)
+            if (any) {
+                reinterpret_cast<float4*>(A.p)[idx[u]] = pp[u];
+                reinterpret_cast<float4*>(A.m)[idx[u]] = mm[u];
+                reinterpret_cast<float4*>(A.v)[idx[u]] = vv[u];
+            }
+        }
+    if (blockIdx.x == A.block0)
+        for (unsigned long long e = A.tail0 + threadIdx.x; e < A.tail1; e += TB)
+            if (adam_vis(vis, n_splats, A, e)) {
+                const float ge = A.g[e];
+                const float me = b1 * A.m[e] + (1.f - b1) * ge, ve = b2 * A.v[e] + (1.f - b2) * ge * ge;
+                A.m[e] = me; A.v[e] = ve;
+                A.p[e] -= A.lr * (me * bc1) / (sqrtf(ve * bc2) + eps);
+            }
+}
+
 static int grid_for(size_t count) {
     size_t b = (count / 4 + TB - 1) / TB;
     if (b < 1) b = 1;
@@ -99,6 +177,40 @@ int dvs_adam_step(void* stream, float* param, const float* grad, float* m, float
     const float bc1 = 1.0f / (1.0f - powf(beta1, (float)step)), bc2 = 1.0f / (1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(k_adam, dim3(grid_for(count)), dim3(TB), 0, (hipStream_t)stream, param, grad, m, v, count, lr, beta1, beta2,
                        eps, bc1, bc2);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_adam_step_groups(void* stream, const dvs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int step,
+                         const int32_t* visible, int32_t n_splats) {
+    if (!groups || n_groups < 1 || n_groups > DVS_ADAM_MAX_GROUPS || step < 1) return DVS_ERR_INVALID;
+    AdamGroupsDev G{};
+    unsigned long long blocks = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        const dvs_adam_group& a = groups[k];
+        AdamGroupDev& d = G.g[G.n];
+        if (a.count == 0) continue;
+        if (!a.param || !a.grad || !a.m || !a.v || a.width < 1) return DVS_ERR_INVALID;
+        const bool tiled = a.layout == DVS_SHN_TILED;
+        if (tiled && (a.width != 45 || a.count % DVS_SHN_TILE_FLOATS != 0 || a.active_chunks < 0 || a.active_chunks > 12)) return DVS_ERR_INVALID;
+        if (!tiled && a.layout != DVS_SHN_ROWS) return DVS_ERR_INVALID;
+        d.p = a.param; d.g = a.grad; d.m = a.m; d.v = a.v; d.lr = a.lr; d.width = a.width; d.tiled = tiled ? 1 : 0;
+        if (tiled) {
+            d.active_vec = (a.active_chunks ? a.active_chunks : 12) * 64;
+            d.nvec = (a.count / DVS_SHN_TILE_FLOATS) * (unsigned long long)d.active_vec;
+            d.tail0 = d.tail1 = 0;
+        } else {
+            d.active_vec = 0;
+            d.nvec = a.count >> 2; d.tail0 = d.nvec << 2; d.tail1 = a.count;
+        }
+        d.block0 = (unsigned)blocks;
+        unsigned long long b = (d.nvec + TB * ADAM_VPT - 1) / (TB * ADAM_VPT);
+        if (b < 1) b = 1;                   // the tail loop runs in the group's first workgroup
+        blocks += b;
+        ++G.n;
+    }
+    if (G.n == 0) return DVS_OK;
+    if (blocks > 0x7fffffffull) return DVS_ERR_INVALID;
+    const float bc1 = 1.0f / (1.0f - powf(beta1, (float)step)), bc2 = 1.0f / (1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(k_adam_groups, dim3((unsigned)blocks), dim3(TB), 0, (hipStream_t)stream, G, visible, n_splats, beta1, beta2, eps, bc1, bc2);
     return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
 }
 }

@@ -66,7 +66,7 @@ struct GaussianTrainerScene::Impl {
     dvs_fwd_state fwd{};
     std::vector<dvs_camera> cams;
     std::vector<float*> d_targets;
-    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0] = (1-w) L1, d_loss[1] = sum of the SSIM map
+    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0] = (1-w) L1, d_loss[1..64] = SSIM partial sums
     float* d_ssim_maps[3] = {nullptr, nullptr, nullptr};
     float last_loss = 0.f;
     int step = 0;
@@ -184,8 +184,8 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     const size_t img = 3 * (size_t)W * H;
     HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
-    HIP_OR_THROW(hipMalloc((void**)&d_loss, 2 * sizeof(float)));
-    HIP_OR_THROW(hipMemset(d_loss, 0, 2 * sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_loss, (1 + DVS_SSIM_SLOTS) * sizeof(float)));
+    HIP_OR_THROW(hipMemset(d_loss, 0, (1 + DVS_SSIM_SLOTS) * sizeof(float)));
     if (cfg.ssimWeight > 0.f)
         for (int k = 0; k < 3; ++k) HIP_OR_THROW(hipMalloc((void**)&d_ssim_maps[k], img * sizeof(float)));
     dvs_opts opts{sh_max, cfg.mipAntiliased ? 1 : 0, 0, 0, DVS_SHN_TILED};
@@ -324,7 +324,7 @@ void GaussianTrainerScene::trainStep() {
     DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, &m.fwd, nullptr));
     // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25); its gradient goes straight into d_dL
     const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
-    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, 2 * sizeof(float), m.stream));
+    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, (1 + DVS_SSIM_SLOTS) * sizeof(float), m.stream));
     DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, 1.f - w_ssim, m.d_dL, m.d_loss));
     if (w_ssim > 0.f) {
         DVS_OR_THROW(dvs_ssim_forward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
@@ -343,9 +343,16 @@ void GaussianTrainerScene::trainStep() {
     const float t = std::min(1.0f, (float)m.step / (float)std::max(1, m.cfg.numIters));
     const float lr_pos = std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
     const float lr[6] = {lr_pos, m.cfg.featurelr, m.cfg.featurelr / 20.f, m.cfg.opacitylr, m.cfg.scalinglr, m.cfg.rotationlr};
-    for (int k = 0; k < 6; ++k)
-        DVS_OR_THROW(dvs_adam_step(m.stream, m.d_param[k], m.d_grad[k], m.d_m[k], m.d_v[k], m.dev_floats(k), lr[k], 0.9f, 0.999f,
-                                   1e-15f, it));
+    // one launch for the six groups; shN chunks above the active SH degree have g = m = v = 0 (Adam is the identity there)
+    static const int width[6] = {3, 3, 45, 1, 3, 4};
+    dvs_adam_group ag[6];
+    for (int k = 0; k < 6; ++k) {
+        ag[k] = dvs_adam_group{m.d_param[k], m.d_grad[k], m.d_m[k], m.d_v[k], (uint64_t)m.dev_floats(k), lr[k], width[k],
+                               k == P_SHN ? DVS_SHN_TILED : DVS_SHN_ROWS, 0};
+        if (k == P_SHN) ag[k].active_chunks = deg >= 3 ? 0 : (3 * ((deg + 1) * (deg + 1) - 1) + 3) / 4;
+    }
+    if (deg == 0) ag[P_SHN].count = 0;
+    DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, m.cfg.visibleAdam ? m.fwd.radii : nullptr, m.n));
     if (refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0) m.densify(it);
     if (refining && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0)
         DVS_OR_THROW(dvs_reset_opacity(m.stream, m.n, m.d_param[P_OPA], 0.01f, m.d_m[P_OPA], m.d_v[P_OPA]));
@@ -378,11 +385,13 @@ int GaussianTrainerScene::getCurrentIterations() const { return impl_->step; }
 float GaussianTrainerScene::getCurrentLoss() {
     Impl& m = *impl_;
     if (m.d_loss && m.stream) {
-        float h[2] = {0.f, 0.f};
+        float h[1 + DVS_SSIM_SLOTS] = {0.f};
         (void)hipStreamSynchronize(m.stream);
-        (void)hipMemcpy(h, m.d_loss, 2 * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, m.d_loss, sizeof h, hipMemcpyDeviceToHost);
         const float w = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
-        m.last_loss = h[0] + (w > 0.f ? w * (1.f - h[1] / (3.f * (float)m.W * (float)m.H)) : 0.f);
+        double ssim_sum = 0;
+        for (int k = 1; k <= DVS_SSIM_SLOTS; ++k) ssim_sum += h[k];
+        m.last_loss = h[0] + (w > 0.f ? w * (1.f - (float)(ssim_sum / (3.0 * m.W * m.H))) : 0.f);
     }
     return m.last_loss;
 }

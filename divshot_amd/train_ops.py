@@ -1,7 +1,7 @@
 """ctypes wrappers of include/dvs_train.h (loss gradient, SSIM, fused Adam) on torch CUDA tensors."""
 import ctypes as C
 import torch
-from ._lib import lib, check
+from ._lib import lib, check, AdamGroup
 
 
 def _st():
@@ -22,14 +22,14 @@ class Ssim:
     def __init__(self, width, height, device):
         self.W, self.H = width, height
         self.maps = [torch.empty((3, height, width), dtype=torch.float32, device=device) for _ in range(3)]
-        self.sum = torch.zeros(1, dtype=torch.float32, device=device)
+        self.sum = torch.zeros(64, dtype=torch.float32, device=device)        # DVS_SSIM_SLOTS partial sums
 
     def forward(self, img, target):
         """-> mean SSIM as a 1-element tensor (asynchronous)."""
         self.sum.zero_()
         check(lib.dvs_ssim_forward(_st(), img.data_ptr(), target.data_ptr(), self.W, self.H, self.maps[0].data_ptr(),
                                    self.maps[1].data_ptr(), self.maps[2].data_ptr(), self.sum.data_ptr()), "dvs_ssim_forward")
-        return self.sum / (3.0 * self.W * self.H)
+        return self.sum.sum().reshape(1) / (3.0 * self.W * self.H)
 
     def backward(self, img, target, dL, scale, accumulate=True):
         """dL (+)= scale * d(mean SSIM)/d(img)."""
@@ -42,3 +42,16 @@ class Ssim:
 def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-15):
     check(lib.dvs_adam_step(_st(), param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), float(lr), float(beta1),
                             float(beta2), float(eps), int(step)), "dvs_adam_step")
+
+
+def adam_step_groups(groups, step, beta1=0.9, beta2=0.999, eps=1e-15, visible=None):
+    """All parameter groups in one launch. groups: iterable of dicts {param, grad, m, v, lr, width[, tiled, active_chunks]};
+    visible: optional int32 [n] radii tensor -> only splats with radii > 0 are updated (the reference's visibleAdam)."""
+    arr = (AdamGroup * len(groups))()
+    for a, g in zip(arr, groups):
+        a.param, a.grad, a.m, a.v = g["param"].data_ptr(), g["grad"].data_ptr(), g["m"].data_ptr(), g["v"].data_ptr()
+        a.count, a.lr, a.width = g["param"].numel(), float(g["lr"]), int(g["width"])
+        a.layout, a.active_chunks = int(bool(g.get("tiled", False))), int(g.get("active_chunks", 0))
+    check(lib.dvs_adam_step_groups(_st(), arr, len(groups), float(beta1), float(beta2), float(eps), int(step),
+                                   visible.data_ptr() if visible is not None else None, int(visible.numel()) if visible is not None else 0),
+          "dvs_adam_step_groups")

@@ -86,6 +86,7 @@ enum {
                               instruction, no LDS round trip. Element-wise consumers (optimizer, all-reduce) are
                               layout-agnostic; dvs_shn_relayout converts. */
 };
+#define DVS_SHN_TILE_FLOATS 3072   /* floats per 64-splat tile of the DVS_SHN_TILED layout (12 * 64 * 4) */
 
 typedef struct dvs_opts {
     int32_t sh_degree;     /* active SH degree 0..3 */

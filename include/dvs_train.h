@@ -26,9 +26,11 @@ int dvs_l2_loss_grad(void* stream, const float* rgb, const float* target, size_t
  * SSIM with the standard 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 0.01^2, C2 = 0.03^2, per channel, mean over
  * all 3*H*W values. Two fused passes over LDS-staged 16x16 tiles with a 5-pixel halo:
  *   dvs_ssim_forward : img, target [3,H,W] -> per-pixel partial derivative maps (3 x [3,H,W], caller-provided scratch) and
- *                      *ssim_sum += sum of the SSIM map (divide by 3*H*W for the mean);
+ *                      ssim_sum[0..DVS_SSIM_SLOTS) += partial sums of the SSIM map (add the slots, divide by 3*H*W for the mean;
+ *                      several slots because tens of thousands of same-address atomics would serialise);
  *   dvs_ssim_backward: dL_dimg[3,H,W] (+)= scale * d(mean SSIM)/d(img)   (scale = -w to minimise 1 - SSIM; accumulate = add).
  * All pointers DEVICE; asynchronous on `stream`. */
+#define DVS_SSIM_SLOTS 64
 int dvs_ssim_forward(void* stream, const float* img, const float* target, int width, int height, float* dm_dmu1,
                      float* dm_dsigma1_sq, float* dm_dsigma12, float* ssim_sum);
 int dvs_ssim_backward(void* stream, const float* img, const float* target, int width, int height, const float* dm_dmu1,
@@ -38,6 +40,30 @@ int dvs_ssim_backward(void* stream, const float* img, const float* target, int w
  * step is 1-based. Asynchronous. */
 int dvs_adam_step(void* stream, float* param, const float* grad, float* m, float* v, size_t count, float lr, float beta1,
                   float beta2, float eps, int step);
+
+/* All parameter groups of one optimizer step in ONE launch (the trainer has six: pos, sh0, shN, opacity, scale, rot).
+ *   width        floats per splat of the group (3, 45, 1, 4 ...); only used to find the splat of an element when `visible` is given.
+ *   layout       DVS_SHN_ROWS: element e belongs to splat e / width.  DVS_SHN_TILED (width 45 only): the [ceil(n/64)][12][64][4] layout.
+ *   active_chunks  DVS_SHN_TILED only: update just the first active_chunks (1..12) float4 chunks of every splat, 0 = all. While the
+ *                progressive SH degree is below 3 the higher coefficients have g = m = v = 0 and Adam is the identity on them, so
+ *                skipping them is exact (chunks needed for degree d: ceil(3*((d+1)^2-1)/4)).
+ *   visible      nullable int32[n_splats] (dvs_fwd_state.radii of this view): when given, only splats with visible[i] > 0 are updated and
+ *                the moments of the others do not decay — the reference's `visibleAdam` option (gs_train.cpp:87; the "sparse Adam"
+ *                of Taming-3DGS). NULL = dense Adam, identical to dvs_adam_step per group. */
+typedef struct dvs_adam_group {
+    float* param;
+    const float* grad;
+    float* m;
+    float* v;
+    uint64_t count;       /* floats in the arrays (tiled: padded to whole 64-splat tiles) */
+    float lr;
+    int32_t width;
+    int32_t layout;
+    int32_t active_chunks;
+} dvs_adam_group;
+#define DVS_ADAM_MAX_GROUPS 8
+int dvs_adam_step_groups(void* stream, const dvs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int step,
+                         const int32_t* visible, int32_t n_splats);
 
 /* ---- adaptive density control: clone / split / prune, the "ADC" strategy of --densifyStrategy -------------
  * (flags application/diverseshot-cli/source/main.cpp:20,29,46-65: growGrad2d 2e-4, warmupLength 500, refineEvery 100, resetAlphaEvery

@@ -84,6 +84,69 @@ def test_l1_and_adam(gpu_device):
     np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=2e-5, atol=1e-6)
 
 
+def test_adam_groups(gpu_device):
+    """dvs_adam_step_groups: one launch == the per-group kernel (up to FMA contraction); active-chunk skipping is the identity on
+    never-touched coefficients; `visible` freezes invisible splats (the reference's visibleAdam, gs_train.cpp:87)."""
+    import torch
+    from divshot_amd.train_ops import adam_step, adam_step_groups
+    from divshot_amd.raster import shn_rows_to_tiled_np
+    rng = np.random.default_rng(5)
+    n = 1000                                                   # not a multiple of 64: the last shN tile is padded
+    widths = {"pos": 3, "sh0": 3, "shN": 45, "opacity": 1, "scale": 3, "rot": 4}
+    dev = lambda a: torch.tensor(a, device=gpu_device)
+
+    def make(seed, deg=3):
+        r = np.random.default_rng(seed)
+        out = {}
+        for k, w in widths.items():
+            a = [r.standard_normal((n, w)).astype(np.float32) for _ in range(2)] + [np.abs(r.standard_normal((n, w))).astype(np.float32) * 0.1
+                                                                                     for _ in range(2)]
+            if k == "shN" and deg < 3:                          # coefficients above the active degree never saw a gradient
+                lo = 3 * ((deg + 1) ** 2 - 1)
+                for x in a[1:]:
+                    x[:, lo:] = 0
+            if k == "shN":
+                a = [shn_rows_to_tiled_np(x) for x in a]
+            out[k] = [dev(x.reshape(-1)) for x in a]            # param, grad, m, v
+        return out
+
+    def groups(t, active=0):
+        return [dict(param=t[k][0], grad=t[k][1], m=t[k][2], v=t[k][3], lr=1e-2 * (i + 1), width=w, tiled=(k == "shN"),
+                     active_chunks=(active if k == "shN" else 0)) for i, (k, w) in enumerate(widths.items())]
+
+    # 1. dense: same as six dvs_adam_step calls (the two kernels may contract FMAs differently: 1-ulp slack)
+    a, b = make(1), make(1)
+    adam_step_groups(groups(a), 3, eps=1e-8)
+    for i, k in enumerate(widths):
+        adam_step(b[k][0], b[k][1], b[k][2], b[k][3], 1e-2 * (i + 1), 3, eps=1e-8)
+        for x, y in zip(a[k], b[k]):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), k
+    # 2. active chunks at degree 1 (9 floats -> 3 chunks): same result as the dense update
+    a, b = make(2, deg=1), make(2, deg=1)
+    adam_step_groups(groups(a, active=3), 2, eps=1e-15)
+    adam_step_groups(groups(b), 2, eps=1e-15)
+    for k in widths:
+        for x, y in zip(a[k], b[k]):
+            assert torch.equal(x, y), k
+    # 3. visible mask
+    a, b = make(3), make(3)
+    before = {k: [x.clone() for x in a[k]] for k in widths}
+    radii = (rng.random(n) < 0.6).astype(np.int32) * 7
+    adam_step_groups(groups(a), 4, eps=1e-8, visible=dev(radii))
+    adam_step_groups(groups(b), 4, eps=1e-8)
+    vis = radii > 0
+    for k, w in widths.items():
+        if k == "shN":
+            e = np.arange(a[k][0].numel()); splat = (e // 3072) * 64 + ((e % 3072) // 4) % 64
+        else:
+            splat = np.arange(n * w) // w
+        mask = dev((splat < n) & vis[np.minimum(splat, n - 1)])
+        for j in (0, 2, 3):
+            assert torch.equal(a[k][j][mask], b[k][j][mask]), (k, j)
+            assert torch.equal(a[k][j][~mask], before[k][j][~mask]), (k, j)
+    assert (~vis).any() and vis.any()
+
+
 @pytest.mark.parametrize("tiled", [False, True])
 def test_densify_plan_and_apply(gpu_device, tiled):
     """ADC clone / split / prune against a numpy restatement of the rule."""
