@@ -150,13 +150,15 @@ def main():
     inv_P = 1.0 / (W * H)
 
     exchange = args.exchange
-    if exchange == "auto":      # bytes received per splat per rank: ring all-reduce of B bytes ~ 2 (w-1)/w B; all-gather of b bytes ~ (w-1) b
-        ring = 2.0 * (world - 1) / max(world, 1)
-        exchange = "factorised" if (world - 1) * VPS * 12 + ring * 44 < ring * 236 else "allreduce"
+    if exchange == "auto":
+        # exposed bytes received per splat per rank: ring all-reduce of B bytes ~ 2 (w-1)/w B; all-gather of b bytes ~ (w-1) b.
+        # The factorised exchange gathers views 0..VPS-2 under the compute of the following view, so only one gather is exposed:
+        # (w-1) 12 + ring 44 < ring 236 for every world size.
+        exchange = "factorised"
     factorised = dist is not None and exchange == "factorised"
     if factorised:
         fx = FactorisedExchange(n, dev, world, views_per_rank=VPS)
-        campos_all = np.array([list(dv.synth_camera(spec, (r * VPS + v) % n_cams).campos) for r in range(world) for v in range(VPS)], np.float32)
+        campos_all = np.array([list(dv.synth_camera(spec, (r * VPS + v) % n_cams).campos) for r, v in fx.slots()], np.float32)
     bwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
     step_done = torch.cuda.Event()
     main_stream = torch.cuda.current_stream(dev)
@@ -180,6 +182,8 @@ def main():
                 rasts[c].backward(dL, grads=g, accumulate=(v > 0), factorised_sh=factorised)
                 if n_ctx > 1:
                     bwd_done[c].record(st)
+                if factorised and v < VPS - 1:
+                    fx.gather_view(v, bwd_done[c] if n_ctx > 1 else None)      # overlaps with the next view's kernels
         if n_ctx > 1:
             main_stream.wait_event(bwd_done[(VPS - 1) % n_ctx])
         if factorised:

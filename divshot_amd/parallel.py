@@ -61,30 +61,65 @@ class FactorisedExchange:
     all-gathers the other ranks' gc (3 floats per splat per view) and rebuilds the summed SH rows locally with
     dvs_sh_grad_combine, from its own replica of the positions and the views' camera centres. Only the 11 geometry
     floats (pos, scale, rot, opacity) go through the sum-all-reduce. Per-GPU wire volume at 8 GPUs and 1M splats:
-    ring all-reduce of 236 MB ~ 413 MB  ->  all-reduce of 44 MB (77 MB) + all-gather of 8 x 12 MB (84 MB received).
+    ring all-reduce of 236 MB ~ 413 MB  ->  all-reduce of 44 MB (77 MB) + per view an all-gather of 8 x 12 MB (84 MB received).
+    With several views per rank and step, the gather of view v runs on a side stream under the compute of view v+1
+    (gather_view), so the exposed part stays one gather + the geometry all-reduce however many views a step has.
     On MI355X's point-to-point xGMI links the exchange is bandwidth-bound, so this is ~2.5x less exposed time.
     """
 
     def __init__(self, n, device, world, views_per_rank=1):
         self.n, self.world, self.views_per_rank = n, world, views_per_rank
-        # dcolor_local[v] = colour gradient of this rank's v-th view; dcolor_all[r*V + v] after the all-gather
+        # dcolor_local[v] = colour gradient of this rank's v-th view; after the all-gathers dcolor_all[v*world + r] = view v of
+        # rank r (view-major, so the slots of one view are one contiguous all-gather output; `slots()` lists the order)
         self.dcolor_local = torch.zeros((views_per_rank, n, 3), dtype=torch.float32, device=device)
         self.dcolor_all = torch.zeros((world * views_per_rank, n, 3), dtype=torch.float32, device=device)
+        self._gathered = [False] * views_per_rank
+        self._comm = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+
+    def slots(self):
+        """[(rank, local_view)] for every slot of dcolor_all, in order — index the per-view camera table with this."""
+        return [(r, v) for v in range(self.views_per_rank) for r in range(self.world)]
+
+    def _gather(self, v, group):
+        import torch.distributed as dist
+        out = self.dcolor_all[v * self.world:(v + 1) * self.world]
+        if self.world == 1:
+            out[0].copy_(self.dcolor_local[v])
+            return
+        try:
+            dist.all_gather_into_tensor(out.view(-1), self.dcolor_local[v].view(-1), group=group)
+        except (RuntimeError, NotImplementedError):      # backends without the flat form (gloo on some builds)
+            dist.all_gather(list(out.unbind(0)), self.dcolor_local[v], group=group)
+
+    def gather_view(self, v, ready=None, group=None):
+        """Start the all-gather of local view v as soon as its backward has produced dcolor_local[v] (`ready`: a CUDA event
+        recorded after that backward). It runs on a side stream, under the composite kernels of the following views, so only
+        the last view's gather and the small geometry all-reduce stay exposed at the end of the step."""
+        if self._comm is None:
+            self._gather(v, group)
+        else:
+            if ready is not None:
+                self._comm.wait_event(ready)
+            else:
+                self._comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                self._gather(v, group)
+        self._gathered[v] = True
 
     def communicate(self, gbuf, group=None):
-        """all-reduce(geometry slice) + all-gather(dcolor). Returns when both are complete on the current stream."""
+        """all-gather of the views not gathered yet + all-reduce(geometry slice). Complete on the current stream on return."""
         import torch.distributed as dist
-        if self.world == 1:
-            self.dcolor_all.copy_(self.dcolor_local)
-            return
-        work = dist.all_reduce(gbuf.flat_geom, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        try:
-            dist.all_gather_into_tensor(self.dcolor_all.view(-1), self.dcolor_local.view(-1), group=group)
-        except (RuntimeError, NotImplementedError):      # backends without the flat form (gloo on some builds)
-            dist.all_gather(list(self.dcolor_all.unbind(0)), self.dcolor_local, group=group)
-        work.wait()
+        for v in range(self.views_per_rank):
+            if not self._gathered[v]:
+                self.gather_view(v, None, group)
+        self._gathered = [False] * self.views_per_rank
+        if self.world > 1:
+            dist.all_reduce(gbuf.flat_geom, op=dist.ReduceOp.SUM, group=group)
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
 
     def exchange(self, gbuf, rast, pos, campos_all, sh_degree, group=None, shn_tiled=False):
-        """Full exchange: after this, every view of gbuf holds the sum over all ranks' views."""
+        """Full exchange: after this, every view of gbuf holds the sum over all ranks' views. campos_all[s] is the camera
+        centre of slot s (see slots())."""
         self.communicate(gbuf, group)
         rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree, shn_tiled=shn_tiled)

@@ -40,16 +40,25 @@ def _worker_fact(rank, world, port, n, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gb = GradBuffer(n, torch.device("cpu"))
-    fx = FactorisedExchange(n, torch.device("cpu"), world)
-    gb.flat_geom += (rank + 1) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
-    gb.flat_sh.fill_(-1.0)                                   # must not be touched by the communication
-    fx.dcolor_local[0].copy_((rank + 1) * torch.ones((n, 3)) + torch.arange(n, dtype=torch.float32)[:, None])
-    fx.communicate(gb)
-    want = sum(range(1, world + 1)) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
-    assert torch.allclose(gb.flat_geom, want, rtol=1e-6)
-    assert bool((gb.flat_sh == -1.0).all())
-    for r in range(world):                                   # gathered in rank order
-        assert torch.equal(fx.dcolor_all[r], (r + 1) * torch.ones((n, 3)) + torch.arange(n, dtype=torch.float32)[:, None])
+    V = 2                                                    # views per rank and step
+    fx = FactorisedExchange(n, torch.device("cpu"), world, views_per_rank=V)
+    ramp = torch.arange(n, dtype=torch.float32)[:, None]
+    val = lambda r, v: (10 * v + r + 1) * torch.ones((n, 3)) + ramp
+    for step in range(2):                                    # two steps: the per-step gather bookkeeping resets
+        gb.flat.zero_()
+        gb.flat_geom += (rank + 1) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+        gb.flat_sh.fill_(-1.0)                               # must not be touched by the communication
+        fx.dcolor_all.fill_(float("nan"))
+        fx.dcolor_local[0].copy_(val(rank, 0))
+        fx.gather_view(0)                                    # early gather of view 0 (on a GPU: under view 1's kernels)
+        fx.dcolor_local[1].copy_(val(rank, 1))
+        fx.communicate(gb)                                   # gathers view 1, all-reduces the geometry slice
+        want = sum(range(1, world + 1)) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+        assert torch.allclose(gb.flat_geom, want, rtol=1e-6)
+        assert bool((gb.flat_sh == -1.0).all())
+        assert fx.slots() == [(r, v) for v in range(V) for r in range(world)]
+        for s_, (r, v) in enumerate(fx.slots()):             # view-major slots
+            assert torch.equal(fx.dcolor_all[s_], val(r, v)), (s_, r, v)
     out.put((rank, float(gb.flat_geom.sum())))
     dist.destroy_process_group()
 
