@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
+    ap.add_argument("--contexts", type=int, default=2, help="rasterizer contexts / HIP streams the views of a step are pipelined over")
     ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
                     help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
                          "12 B per splat per view, SH rows rebuilt locally); auto picks the one that puts fewer bytes on the wire")
@@ -133,7 +134,7 @@ def main():
     params = params_to_device(P, dev)
     # Views of one step are independent, so they are software-pipelined over two rasterizer contexts on two HIP streams:
     # the HBM/latency-bound front of view v+1 (preprocess, sorts) runs under the VALU-bound composite kernels of view v.
-    n_ctx = 2 if VPS > 1 else 1
+    n_ctx = max(1, min(args.contexts, VPS))
     rasts = [Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H) for _ in range(n_ctx)]
     rast = rasts[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)] if n_ctx > 1 else [torch.cuda.current_stream(dev)]

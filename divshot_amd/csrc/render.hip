@@ -4,7 +4,7 @@
 // splat's footprint can be rejected per wave. The tile's depth-ordered splat list is streamed
 // through LDS in batches of 256 (one gathered splat per lane, then broadcast reads).
 // Backward replays the list back-to-front, reduces the 9 (11 with abs-grad) per-splat partials over
-// the 64 lanes with v_permlane32/16_swap + DPP row operations (no LDS traffic) and publishes them with ONE
+// the 64 lanes with v_permlane32/16_swap + ds_swizzle butterflies (LDS crossbar, no LDS memory) and publishes them with ONE
 // hardware fp32 atomic instruction per (wave, splat): 11 lanes add 11 consecutive floats of the splat's
 // 48-byte gradient row (global_atomic_add_f32; built with -munsafe-fp-atomics, no CAS loop).
 //
@@ -24,33 +24,10 @@ __device__ __forceinline__ int tile_of_block(int b, int num_tiles) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
-    // old = 0, bound_ctrl = true: lanes without a source (or masked rows) add 0
-    switch (ctrl) {   // ctrl / row_mask must be immediates
-        case 0xB1:  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-        case 0x4E:  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-        case 0x141: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-        case 0x140: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-        case 0x142: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));
-        default:    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));
-    }
-    (void)row_mask;
-}
-// sum over the 64 lanes; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-    v = dpp_add(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-    v = dpp_add(v, 0x141, 0xF);   // row_half_mirror
-    v = dpp_add(v, 0x140, 0xF);   // row_mirror
-    v = dpp_add(v, 0x142, 0xA);   // row_bcast:15 into rows 1,3
-    v = dpp_add(v, 0x143, 0xC);   // row_bcast:31 into rows 2,3
-    return v;
-}
-
-// 12 per-lane partials -> 12 wave totals in 30 cross-lane instructions (a plain DPP tree needs 6 per value).
+// 12 per-lane partials -> 12 wave totals in 9 VALU swaps + 12 LDS-crossbar swizzles (a plain DPP tree needs 6 DPP adds per value).
 // Two halving steps with the gfx950 swap instructions fold the 64 lanes to 16 while packing 4 values per
 // register (v_permlane32_swap: lanes 32-63 of A <-> lanes 0-31 of B; v_permlane16_swap: odd 16-lane rows of
-// A <-> even rows of B), then a 4-step DPP butterfly finishes inside each 16-lane row.
+// A <-> even rows of B), then a 4-step butterfly (ds_swizzle, see row_sum) finishes inside each 16-lane row.
 // Result: q[k] holds, in every lane of row r, the total of value index kRowValue[k][r]:
 //   q[0] rows -> v0,v2,v1,v3   q[1] rows -> v4,v6,v5,v7   q[2] rows -> v8,v10,v9,v11
 __device__ __forceinline__ float swap32_add(float a, float b) {
@@ -61,11 +38,14 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// 16-lane butterfly through ds_swizzle_b32 (the LDS crossbar; no LDS memory is touched) + a plain v_add per stage: the
+// lane exchange leaves the VALU, which is the unit the backward kernel is bound by (a DPP add costs two VALU slots;
+// measured -9 % kernel time against the DPP butterfly). Every lane of a row ends with the row total.
 __device__ __forceinline__ float row_sum(float v) {
-    v = dpp_add(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-    v = dpp_add(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-    v = dpp_add(v, 0x141, 0xF);   // row_half_mirror
-    v = dpp_add(v, 0x140, 0xF);   // row_mirror
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (1 << 10) | 0x1f));     // xor 1
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (2 << 10) | 0x1f));     // xor 2
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (4 << 10) | 0x1f));     // xor 4
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (8 << 10) | 0x1f));     // xor 8
     return v;
 }
 __device__ __forceinline__ void wave_reduce12(const float v[12], float q[3]) {
@@ -84,11 +64,14 @@ __device__ __forceinline__ void wave_reduce12(const float v[12], float q[3]) {
 // instruction on a splat that cannot touch its pixels. The bound is inflated (1e-4 rel + 1e-3) so the
 // exact per-pixel alpha test — unchanged — decides every contribution: results are identical to a full walk.
 struct __attribute__((aligned(16))) BatchLds {
-    float4 cs[RB];      // (-0.5 log2e a, -log2e b, -0.5 log2e c, opacity): exp(power) = exp2(cs.x dx^2 + cs.y dx dy + cs.z dy^2)
-    float4 co[RB];      // conic a, b, c + opacity as preprocess wrote them (gradient formulas)
-    float4 rgb[RB];
-    float2 xy[RB];
-    uint32_t id[RB];
+    // Four 16-B-stride arrays (one address VGPR serves every read of a visit), packed so that each read is a full
+    // ds_read_b128 or a ds_read_b32 (a 12-byte ds_read_b96 costs twice the LDS cycles of a b128):
+    // the alpha test of a visit needs x, y, cs.xyz, o = one b128 + one b64; the rest is read only by contributing visits.
+    // cs = (-0.5 log2e a, -log2e b, -0.5 log2e c): exp(power) = exp2(cs.x dx^2 + cs.y dx dy + cs.z dy^2)
+    float4 xyc[RB];     // mean x, mean y, cs.x, cs.y
+    float4 zoir[RB];    // cs.z, opacity | splat id bits, colour r
+    float4 cog[RB];     // conic a, b, c as preprocess wrote them (gradient formulas), colour g
+    float4 bl[RB];      // colour b in .x
     uint64_t qmask[RB / 64][4];
 };
 
@@ -101,11 +84,11 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         const uint32_t id = sorted_splat[first + t];
         const float2 xy = mean2d[id];
         const float4 co = conic_opacity[id];
-        L.id[t] = id;
-        L.xy[t] = xy;
-        L.co[t] = co;
-        L.cs[t] = make_float4(-0.72134752044448170f * co.x, -1.4426950408889634f * co.y, -0.72134752044448170f * co.z, co.w);
-        L.rgb[t] = rgb[id];
+        const float4 col = rgb[id];
+        L.xyc[t] = make_float4(xy.x, xy.y, -0.72134752044448170f * co.x, -1.4426950408889634f * co.y);
+        L.zoir[t] = make_float4(-0.72134752044448170f * co.z, co.w, __uint_as_float(id), col.x);
+        L.cog[t] = make_float4(co.x, co.y, co.z, col.y);
+        L.bl[t].x = col.z;
         // The splat can reach alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o), d = pixel - mean.
         // Minimise the convex form q over each quadrant's pixel rectangle (exact: origin inside -> 0, otherwise the
         // minimum lies on one of the four edges) and keep the splat for that quadrant iff the minimum is within the bound.
@@ -173,9 +156,10 @@ k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
             while (m) {
                 const int j = lw * 64 + __builtin_ctzll(m);
                 m &= m - 1;
-                const float2 xy = L.xy[j];
-                const float4 cs = L.cs[j];
-                const float4 c = L.rgb[j];
+                const float4 xy = L.xyc[j];
+                const float4 zo = L.zoir[j];
+                const float4 cs = make_float4(xy.z, xy.w, zo.x, zo.y);
+                const float3 c = make_float3(zo.w, L.cog[j].w, L.bl[j].x);
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
                 // log2 of the Gaussian falloff: p2 = log2e * power (sign unchanged), one v_exp_f32, no extra multiply
                 const float p2 = __builtin_fmaf(cs.z * dy, dy, __builtin_fmaf(cs.y, dy, cs.x * dx) * dx);
@@ -269,8 +253,9 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 m &= ~(1ull << bit);
                 const int j = lw * 64 + bit;
                 const uint32_t k = (uint32_t)(base + j);     // 0-based list position; contributor index k+1
-                const float2 xy = L.xy[j];
-                const float4 cs = L.cs[j];
+                const float4 xy = L.xyc[j];
+                const float2 zo2 = *reinterpret_cast<const float2*>(&L.zoir[j]);
+                const float4 cs = make_float4(xy.z, xy.w, zo2.x, zo2.y);
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
                 const float p2 = __builtin_fmaf(cs.z * dy, dy, __builtin_fmaf(cs.y, dy, cs.x * dx) * dx);   // same expression as the forward
                 const float G = __builtin_amdgcn_exp2f(p2);
@@ -279,8 +264,10 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 const bool contrib = (k < last) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
                 if (!__any(contrib)) continue;
                 // predicated: a non-contributing lane runs with alpha = 0 (T, D unchanged, every partial exactly 0)
-                const float4 c = L.rgb[j];
-                const float4 co = L.co[j];
+                const float4 cg = L.cog[j];
+                const float2 ir = *(reinterpret_cast<const float2*>(&L.zoir[j]) + 1);       // splat id bits (publisher lanes), colour r
+                const float3 c = make_float3(ir.y, cg.w, L.bl[j].x);
+                const float4 co = make_float4(cg.x, cg.y, cg.z, cs.w);
                 const float al = contrib ? alpha : 0.f;
                 const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);        // 1-alpha >= 0.01: v_rcp_f32 (1 ulp) is ample
                 T = T * inv_1ma;
@@ -306,7 +293,7 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 if (publisher) {
                     // 11 lanes, 11 consecutive floats of the splat's row: one global_atomic_add_f32 instruction
                     const float val = lcol == 0 ? q[0] : (lcol == 1 ? q[1] : q[2]);
-                    atomicAdd(&grow[(size_t)L.id[j] * 12 + kv], val);
+                    atomicAdd(&grow[(size_t)__float_as_uint(ir.x) * 12 + kv], val);
                 }
             }
         }
