@@ -3,6 +3,7 @@
 // independent registers; cost = elapsed shader cycles * SIMDs-worth / instructions. Development aid (not product code).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define REP 200
 #define UN 16
@@ -36,6 +37,14 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, long long
     if (OP == 17) { BODY("v_max_f32 %0, %0, %1") }
     if (OP == 18) { BODY("v_cmp_lt_f32 vcc, %0, %1") }
     if (OP == 19) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; u += 2) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[u]) : "v"(y[u]), "v"(x[u + 1])); asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(y[u + 1]) : "v"(y[u]), "v"(x[u + 1])); } } }
+    unsigned long long sm[UN];
+    if (OP >= 20) for (int u = 0; u < UN; ++u) sm[u] = __builtin_amdgcn_readfirstlane(blockIdx.x + u) | 0x100000000ull;
+    if (OP == 20) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; ++u) { asm volatile("s_and_b64 %0, %0, %1" : "+s"(sm[u]) : "s"(sm[(u + 1) % UN]) : "scc"); } } }
+    if (OP == 21) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; ++u) { asm volatile("s_and_b64 %0, %0, %1" : "+s"(sm[u]) : "s"(sm[(u + 1) % UN]) : "scc"); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[u]) : "v"(y[u])); } } }
+    if (OP == 22) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; ++u) { asm volatile("ds_swizzle_b32 %0, %1 offset:swizzle(SWAP,1)" : "=v"(x[u]) : "v"(y[u])); } asm volatile("s_waitcnt lgkmcnt(0)"); } }
+    if (OP == 23) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; ++u) { asm volatile("ds_swizzle_b32 %0, %1 offset:swizzle(SWAP,1)" : "=v"(x[u]) : "v"(y[u])); asm volatile("v_add_f32 %0, %0, %0" : "+v"(y[u])); } asm volatile("s_waitcnt lgkmcnt(0)"); } }
+    if (OP == 24) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; ++u) { asm volatile("s_and_b64 %0, %0, %1" : "+s"(sm[u]) : "s"(sm[(u + 1) % UN]) : "scc"); asm volatile("s_or_b64 %0, %0, %1" : "+s"(sm[u]) : "s"(sm[(u + 2) % UN]) : "scc"); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[u]) : "v"(y[u])); } } }
+    if (OP >= 20) { for (int u = 0; u < UN; ++u) x[0] += (float)(unsigned)(sm[u] & 3); }
     long long t1 = __builtin_readcyclecounter();
     float s = 0; for (int u = 0; u < UN; ++u) s += x[u] + y[u];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -70,9 +79,17 @@ template <class K> void run(const char* name, K kern, float* out, long long* cyc
     printf("%-28s wall %.3f ms  -> %.2f ns per wave-instr per SIMD (= %.2f cycles @2.4GHz); s_memtime delta avg %.0f\n", name, ms,
            ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4, avg);
 }
-int main() {
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int only = argc > 1 ? atoi(argv[1]) : -1;      // >= 0: run just that SALU/LDS test (20..24)
     const int blocks = 2048;     // 8 workgroups per CU, 8 waves per SIMD
     float* out; long long* cyc; hipMalloc(&out, blocks * 256 * 4); hipMalloc(&cyc, blocks * 8);
+    if (only == 20) { run("s_and_b64", k<20>, out, cyc, blocks); return 0; }
+    if (only == 21) { run("s_and_b64 + v_add_f32 (per pair)", k<21>, out, cyc, blocks); return 0; }
+    if (only == 22) { run("ds_swizzle_b32", k<22>, out, cyc, blocks); return 0; }
+    if (only == 23) { run("ds_swizzle_b32 + v_add_f32 (per pair)", k<23>, out, cyc, blocks); return 0; }
+    if (only == 24) { run("2 SALU + v_add_f32 (per triple)", k<24>, out, cyc, blocks); return 0; }
+    if (only == 15) { run("v_add_f32", k<15>, out, cyc, blocks); return 0; }
     run("v_fma_f32", k<0>, out, cyc, blocks); run("v_permlane32_swap", k<1>, out, cyc, blocks); run("v_permlane16_swap", k<2>, out, cyc, blocks);
     run("v_add_f32_dpp quad_perm", k<3>, out, cyc, blocks); run("v_add_f32_dpp row_half_mirror", k<4>, out, cyc, blocks);
     run("v_add_f32_dpp row_bcast15", k<5>, out, cyc, blocks); run("v_exp_f32", k<6>, out, cyc, blocks); run("v_rcp_f32", k<7>, out, cyc, blocks);
