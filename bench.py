@@ -175,12 +175,15 @@ def main():
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
                 img = rasts[c].forward(params, cams[v], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled)
                 dL = (img - targets[v]) * inv_P
-                if n_ctx > 1 and v > 0:
-                    st.wait_event(bwd_done[(v - 1) % n_ctx])      # gradient rows are accumulated in view order
                 g = grads
                 if factorised:
                     g = dict(grads); g["dcolor"] = fx.dcolor_local[v]
-                rasts[c].backward(dL, grads=g, accumulate=(v > 0), factorised_sh=factorised)
+                # A8 (composite backward) writes only this context's intermediate rows: it needs no ordering against the other
+                # view. Only A9, which accumulates into the shared gradient rows non-atomically, runs in view order.
+                rasts[c].backward_composite(dL)
+                if n_ctx > 1 and v > 0:
+                    st.wait_event(bwd_done[(v - 1) % n_ctx])
+                rasts[c].backward_project(grads=g, accumulate=(v > 0), factorised_sh=factorised)
                 if n_ctx > 1:
                     bwd_done[c].record(st)
                 if factorised and v < VPS - 1:

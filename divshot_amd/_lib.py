@@ -70,6 +70,9 @@ _PROTOS = {
                                      C.c_void_p, C.POINTER(FwdState), C.POINTER(C.c_uint64)]),
     "dvs_raster_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
                                       C.c_void_p, C.POINTER(SplatGrads)]),
+    "dvs_raster_backward_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.POINTER(Opts), C.c_void_p]),
+    "dvs_raster_backward_project": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
+                                              C.POINTER(SplatGrads)]),
     "dvs_sh_grad_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]),
     "dvs_shn_relayout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

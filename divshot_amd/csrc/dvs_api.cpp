@@ -75,6 +75,7 @@ struct dvs_ctx {
     bool have_fwd = false;
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
+    bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
     // stage timing
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -197,6 +198,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     const int tiles_x = (W + DVS_TILE - 1) / DVS_TILE, tiles_y = (H + DVS_TILE - 1) / DVS_TILE, tiles = tiles_x * tiles_y;
     const DvsCam dcam = to_dev_cam(*cam);
     c->have_fwd = false;
+    c->rows_pending = false;
     timing_reset(c);
     StageTimer tm(c, st);
 
@@ -265,37 +267,85 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     return DVS_OK;
 }
 
-int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
-                        const float* dL_drgb, const dvs_splat_grads* out) {
-    if (!c || !p || !cam || !opts || !dL_drgb || !out) { g_last_error = "dvs_raster_backward: null argument"; return DVS_ERR_INVALID; }
-    if (!c->have_fwd || c->st.n != p->n || c->st.width != cam->width || c->st.height != cam->height) {
-        g_last_error = "dvs_raster_backward: no matching forward on this context"; return DVS_ERR_STATE;
-    }
-    if (p->n > 0 && (!out->pos || !out->opacity || !out->scale || !out->rot || ((!out->sh0 || !out->shN) && !out->dcolor))) {
-        g_last_error = "dvs_raster_backward: null gradient row pointer (sh0/shN may be NULL only when dcolor is given)"; return DVS_ERR_INVALID;
-    }
-    HIPCHECK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    const int n = p->n;
+// A8: zero the 48-B rows if needed, then the alpha-composite backward into them
+static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb, StageTimer* tm) {
     const dvs_fwd_state& s = c->st;
-    const DvsCam dcam = to_dev_cam(*cam);
-    timing_reset(c);
-    StageTimer tm(c, st);
-    size_t e0 = tm.mark();
+    size_t e0 = tm ? tm->mark() : 0;
     if (!c->rows_clean) HIPCHECK(hipMemsetAsync(c->g_rows.p, 0, c->g_rows.bytes, st));
     c->rows_clean = false;
-    size_t e1 = tm.mark(); tm.span("bwd_zero", e0, e1);
+    size_t e1 = tm ? tm->mark() : 0;
+    if (tm) tm->span("bwd_zero", e0, e1);
     HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.mean2d, s.conic_opacity,
                                    s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
-    size_t e2 = tm.mark(); tm.span("render_bwd", e1, e2);
-    HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
+    if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
+    c->rows_pending = true;
+    return DVS_OK;
+}
+// A9: rows -> parameter gradients (re-zeroes the rows it reads)
+static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                       const dvs_splat_grads* out, StageTimer* tm) {
+    const dvs_fwd_state& s = c->st;
+    const DvsCam dcam = to_dev_cam(*cam);
+    size_t e2 = tm ? tm->mark() : 0;
+    HIPCHECK(dvs_launch_preprocess_bwd(st, p->n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
                                        s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
                                        out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor,
                                        opts->accumulate, c->keep_rows ? 0 : 1, opts->shn_layout));
     c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
-    size_t e3 = tm.mark(); tm.span("preprocess_bwd", e2, e3);
+    c->rows_pending = false;
+    if (tm) { size_t e3 = tm->mark(); tm->span("preprocess_bwd", e2, e3); }
+    return DVS_OK;
+}
+static int check_bwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts, const char* who) {
+    static thread_local std::string msg;
+    if (!c || !cam || !opts) { msg = std::string(who) + ": null argument"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
+    if (!c->have_fwd || (p && c->st.n != p->n) || c->st.width != cam->width || c->st.height != cam->height) {
+        msg = std::string(who) + ": no matching forward on this context"; g_last_error = msg.c_str(); return DVS_ERR_STATE;
+    }
+    return DVS_OK;
+}
+static int check_grads(const dvs_splats* p, const dvs_splat_grads* out, const char* who) {
+    static thread_local std::string msg;
+    if (!p || !out) { msg = std::string(who) + ": null argument"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
+    if (p->n > 0 && (!out->pos || !out->opacity || !out->scale || !out->rot || ((!out->sh0 || !out->shN) && !out->dcolor))) {
+        msg = std::string(who) + ": null gradient row pointer (sh0/shN may be NULL only when dcolor is given)";
+        g_last_error = msg.c_str(); return DVS_ERR_INVALID;
+    }
+    return DVS_OK;
+}
+
+int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                        const float* dL_drgb, const dvs_splat_grads* out) {
+    int r;
+    if (!dL_drgb) { g_last_error = "dvs_raster_backward: null argument"; return DVS_ERR_INVALID; }
+    if ((r = check_grads(p, out, "dvs_raster_backward")) != DVS_OK) return r;
+    if ((r = check_bwd_args(c, p, cam, opts, "dvs_raster_backward")) != DVS_OK) return r;
+    HIPCHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    timing_reset(c);
+    StageTimer tm(c, st);
+    if ((r = bwd_composite(c, st, cam, opts, dL_drgb, &tm)) != DVS_OK) return r;
+    if ((r = bwd_project(c, st, p, cam, opts, out, &tm)) != DVS_OK) return r;
     if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, true); }
     return DVS_OK;
+}
+
+int dvs_raster_backward_composite(dvs_ctx* c, void* stream, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb) {
+    int r;
+    if (!dL_drgb) { g_last_error = "dvs_raster_backward_composite: null argument"; return DVS_ERR_INVALID; }
+    if ((r = check_bwd_args(c, nullptr, cam, opts, "dvs_raster_backward_composite")) != DVS_OK) return r;
+    HIPCHECK(hipSetDevice(c->device));
+    return bwd_composite(c, (hipStream_t)stream, cam, opts, dL_drgb, nullptr);
+}
+
+int dvs_raster_backward_project(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                                const dvs_splat_grads* out) {
+    int r;
+    if ((r = check_grads(p, out, "dvs_raster_backward_project")) != DVS_OK) return r;
+    if ((r = check_bwd_args(c, p, cam, opts, "dvs_raster_backward_project")) != DVS_OK) return r;
+    if (!c->rows_pending) { g_last_error = "dvs_raster_backward_project: no dvs_raster_backward_composite on this context"; return DVS_ERR_STATE; }
+    HIPCHECK(hipSetDevice(c->device));
+    return bwd_project(c, (hipStream_t)stream, p, cam, opts, out, nullptr);
 }
 
 int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals, uint64_t n, int bit_lo, int bit_hi) {

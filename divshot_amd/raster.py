@@ -109,11 +109,8 @@ class Rasterizer:
         self.num_rendered = int(T.value)
         return out
 
-    def backward(self, dL_drgb, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
-        """dL_drgb: CUDA [3,H,W]. Returns dict of gradient tensors shaped like params (+absgrad2d / mean2d).
-        factorised_sh=True: the sh0/shN rows are NOT written; grads["dcolor"] [n,3] is (see sh_grad_combine)."""
-        assert self.state is not None, "forward first"
-        params, cam = self._params, self._cam
+    def _grad_args(self, grads, accumulate, want_mean2d, factorised_sh):
+        params = self._params
         n = params["pos"].shape[0]
         if grads is None:
             grads = {k: torch.empty_like(params[k]) for k in PARAM_KEYS}
@@ -134,11 +131,35 @@ class Rasterizer:
                        grads["absgrad2d"].data_ptr() if "absgrad2d" in grads else None,
                        grads["mean2d"].data_ptr() if "mean2d" in grads else None,
                        grads["dcolor"].data_ptr() if factorised_sh else None)
-        sp = self._splats(params, self._tiled)
+        return grads, opts, g
+
+    def backward(self, dL_drgb, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
+        """dL_drgb: CUDA [3,H,W]. Returns dict of gradient tensors shaped like params (+absgrad2d / mean2d).
+        factorised_sh=True: the sh0/shN rows are NOT written; grads["dcolor"] [n,3] is (see sh_grad_combine)."""
+        assert self.state is not None, "forward first"
+        grads, opts, g = self._grad_args(grads, accumulate, want_mean2d, factorised_sh)
+        sp = self._splats(self._params, self._tiled)
         assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous()
         with torch.cuda.device(self.tdev):
-            check(lib.dvs_raster_backward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(cam), C.byref(opts),
+            check(lib.dvs_raster_backward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(self._cam), C.byref(opts),
                                           dL_drgb.data_ptr(), C.byref(g)), "dvs_raster_backward")
+        return grads
+
+    def backward_composite(self, dL_drgb):
+        """A8 alone (dvs_raster_backward_composite): touches only this context's intermediate rows."""
+        assert self.state is not None, "forward first"
+        assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous()
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_backward_composite(self.ctx, _stream_ptr(), C.byref(self._cam), C.byref(self._opts), dL_drgb.data_ptr()),
+                  "dvs_raster_backward_composite")
+
+    def backward_project(self, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
+        """A9 alone (dvs_raster_backward_project) after backward_composite; same arguments and result as backward()."""
+        grads, opts, g = self._grad_args(grads, accumulate, want_mean2d, factorised_sh)
+        sp = self._splats(self._params, self._tiled)
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_backward_project(self.ctx, _stream_ptr(), C.byref(sp), C.byref(self._cam), C.byref(opts), C.byref(g)),
+                  "dvs_raster_backward_project")
         return grads
 
     def sh_grad_combine(self, pos, campos, dcolor_all, g_sh0, g_shN, sh_degree, accumulate=False, shn_tiled=False):

@@ -155,6 +155,17 @@ int dvs_raster_forward(dvs_ctx* ctx, void* stream, const dvs_splats* params, con
 int dvs_raster_backward(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                         const dvs_opts* opts, const float* dL_drgb, const dvs_splat_grads* out);
 
+/* The two halves of dvs_raster_backward as separate calls, for callers that batch several
+ * views per optimizer step on several contexts/streams:
+ *   _composite : A8 only — needs just the forward state and dL_drgb; writes the context's own 48-B intermediate rows, so the
+ *                composite backward of view v+1 may run concurrently with anything of view v;
+ *   _project   : A9 — turns those rows into parameter gradients. With opts->accumulate it adds into `out` non-atomically, so
+ *                the _project calls that share gradient arrays must be ordered (an event between streams); nothing else must.
+ * dvs_raster_backward == _composite followed by _project on the same stream (bit-identical results). */
+int dvs_raster_backward_composite(dvs_ctx* ctx, void* stream, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb);
+int dvs_raster_backward_project(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
+                                const dvs_opts* opts, const dvs_splat_grads* out);
+
 /* Rebuild SH gradient rows from per-view colour gradients: for every view v and splat i with dir = normalize(pos_i - campos_v):
  *   g_sh0[i] (+)= SH_C0 * dcolor[v,i],   g_shN[i,k] (+)= basis_k(dir) * dcolor[v,i].
  * This is exactly what dvs_raster_backward writes into sh0/shN for one view, summed over views; it lets data-parallel ranks

@@ -165,6 +165,56 @@ def test_accumulate_two_views(rast, oracle_mod):
         assert m.all(), (k, worst)
 
 
+def test_split_backward_two_contexts(gpu_device):
+    """dvs_raster_backward_composite + _project == dvs_raster_backward (A8 and A9 as separate calls); two views on
+    two contexts and two streams, composites unordered, projects ordered by an event, accumulate into shared rows; and the
+    state errors of the split API."""
+    import torch
+    from divshot_amd import DvsError
+    from divshot_amd.raster import Rasterizer, params_to_device
+    dev = torch.device(gpu_device)
+    spec = dv.make_spec(6000, 160, 96, sh_degree=3, n_cams=3)
+    P = dv.synth_splats(spec)
+    Pd = params_to_device(P, dev)
+    rasts = [Rasterizer(dev.index or 0, max_splats=6000, max_w=160, max_h=96) for _ in range(2)]
+    cams = [dv.synth_camera(spec, ci) for ci in (0, 2)]
+    tgts = [torch.from_numpy(dv.synth_target(spec, ci)).to(dev) for ci in (0, 2)]
+    # reference: fused calls, sequential accumulation on one context
+    ref = None
+    for cam, tgt in zip(cams, tgts):
+        img = rasts[0].forward(Pd, cam, sh_degree=3, absgrad=True)
+        dL = ((img - tgt) / tgt[0].numel()).contiguous()
+        ref = rasts[0].backward(dL) if ref is None else rasts[0].backward(dL, grads=ref, accumulate=True)
+    ref = {k: v.clone() for k, v in ref.items()}
+    torch.cuda.synchronize()
+    # split: each view on its own context and stream
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+    grads = {k: torch.empty_like(Pd[k]) for k in KEYS}
+    grads["absgrad2d"] = torch.empty((6000, 2), dtype=torch.float32, device=dev)
+    keep = []
+    for v in range(2):
+        with torch.cuda.stream(streams[v]):
+            img = rasts[v].forward(Pd, cams[v], sh_degree=3, absgrad=True)
+            dL = ((img - tgts[v]) / tgts[v][0].numel()).contiguous()
+            keep.append(dL)
+            rasts[v].backward_composite(dL)
+            if v > 0:
+                streams[v].wait_event(done[v - 1])
+            rasts[v].backward_project(grads=grads, accumulate=(v > 0))
+            done[v].record(streams[v])
+    torch.cuda.synchronize()
+    for k in list(KEYS) + ["absgrad2d"]:
+        m, worst = rel_close(grads[k].cpu().numpy(), ref[k].cpu().numpy(), 1e-4, 2e-6)      # fp32 atomics: not bit-reproducible
+        assert m.all(), (k, worst)
+    # state errors: project without composite, composite without forward
+    with pytest.raises(DvsError):
+        rasts[0].backward_project(grads=grads)
+    fresh = Rasterizer(dev.index or 0, max_splats=16, max_w=32, max_h=32)
+    with pytest.raises((DvsError, AssertionError)):
+        fresh.backward_composite(keep[0])
+
+
 def test_factorised_sh_gradient(rast):
     """dvs_sh_grad_combine over V views == sum over views of the sh0/shN rows dvs_raster_backward writes:
     the multi-GPU exchange ships dcolor (12 B/splat/view) instead of the 192-B SH rows."""
@@ -325,6 +375,19 @@ def test_edge_cases(rast, oracle_mod):
     r = saved["ranges"]
     assert (r[:, 1] - r[:, 0]).max() > 256
     assert (saved["final_T"] < 2e-4).any()
+    # a tile list with more than 65 536 entries (SURVEY.md §8(c) edge fixture): 70k faint 1-px splats over one tile; alpha only
+    # just clears 1/255 near each centre, so no pixel saturates and every wave walks the whole list (274 LDS batches)
+    n = 70_000
+    P = mk(n); P["pos"][:, 2] = rng.uniform(4.0, 6.0, n).astype(np.float32)
+    px = rng.uniform(32.0, 48.0, n); py = rng.uniform(16.0, 32.0, n)               # tile (2, 1) of the 80x48 image
+    P["pos"][:, 0] = ((px - (80 - 1) / 2) * P["pos"][:, 2] / fx).astype(np.float32)
+    P["pos"][:, 1] = ((py - (48 - 1) / 2) * P["pos"][:, 2] / fx).astype(np.float32)
+    P["scale"][:] = np.log(0.8 * P["pos"][:, 2] / fx)[:, None].astype(np.float32)   # sigma ~ 0.8 px (+0.3 low-pass)
+    P["opacity"][:] = np.float32(np.log(0.0047 / (1 - 0.0047))); P["sh0"][:] = rng.normal(0, 1, (n, 3))
+    img, saved, o = run(P)
+    r = saved["ranges"]
+    assert (r[:, 1] - r[:, 0]).max() > 65536
+    assert saved["final_T"].min() > 1e-3 and saved["n_contrib"].max() > 65536
 
 
 def test_sort_pairs(rast):
