@@ -57,6 +57,10 @@ class AdamGroup(C.Structure):
                 ("lr", C.c_float), ("width", C.c_int32), ("layout", C.c_int32), ("active_chunks", C.c_int32)]
 
 
+class McmcSets(C.Structure):
+    _fields_ = [("param", C.c_void_p * 6), ("m", C.c_void_p * 6), ("v", C.c_void_p * 6)]
+
+
 class SceneSpec(C.Structure):
     _fields_ = [("n", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sh_degree", C.c_int32),
                 ("n_cams", C.c_int32), ("seed", C.c_uint64), ("fov_x_deg", C.c_float), ("scale_log_offset", C.c_float)]
@@ -105,6 +109,12 @@ _PROTOS = {
     "dvs_reset_opacity": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "dvs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int]),
+    "dvs_mcmc_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "dvs_mcmc_init_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "dvs_mcmc_relocate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(McmcSets), C.c_float, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dvs_mcmc_grow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(McmcSets), C.c_float, C.c_uint32, C.c_int, C.c_void_p, C.c_int]),
+    "dvs_mcmc_add_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]),
+    "dvs_mcmc_regularize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "dvs_adam_step_groups": (C.c_int, [C.c_void_p, C.POINTER(AdamGroup), C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p,
                                        C.c_int32]),
 }

@@ -62,6 +62,7 @@ struct GaussianTrainerScene::Impl {
     int cap = 0;                                                             // array capacity in splats (cfg.capMax)
     float* d_grad_accum = nullptr; float* d_denom = nullptr; int* d_max_radii = nullptr;
     uint8_t* d_action = nullptr; uint32_t* d_offsets = nullptr; uint32_t* d_dscratch = nullptr; uint64_t* d_newcount = nullptr;
+    void* d_mcmc = nullptr;                                                  // dvs_mcmc_* scratch (densifyStrategy 1)
     float extent = 1.f;                                                      // scene extent (camera spread), sets the split/clone scale
     dvs_fwd_state fwd{};
     std::vector<dvs_camera> cams;
@@ -82,7 +83,7 @@ struct GaussianTrainerScene::Impl {
             for (float** p : {&d_param[g], &d_grad[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         }
         for (void** p : {(void**)&d_grad_accum, (void**)&d_denom, (void**)&d_max_radii, (void**)&d_action, (void**)&d_offsets,
-                         (void**)&d_dscratch, (void**)&d_newcount}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+                         (void**)&d_dscratch, (void**)&d_newcount, &d_mcmc}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         for (float* t : d_targets) (void)hipFree(t);
         d_targets.clear();
         for (float** p : {&d_absgrad, &d_out, &d_dL, &d_loss, &d_ssim_maps[0], &d_ssim_maps[1], &d_ssim_maps[2]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -117,6 +118,8 @@ struct GaussianTrainerScene::Impl {
         HIP_OR_THROW(hipMalloc((void**)&d_max_radii, (size_t)cap * 4 + 4)); HIP_OR_THROW(hipMalloc((void**)&d_action, (size_t)cap + 4));
         HIP_OR_THROW(hipMalloc((void**)&d_offsets, (size_t)cap * 4 + 4)); HIP_OR_THROW(hipMalloc((void**)&d_dscratch, ((size_t)cap / 256 + 8) * 4));
         HIP_OR_THROW(hipMalloc((void**)&d_newcount, 8));
+        HIP_OR_THROW(hipMalloc(&d_mcmc, dvs_mcmc_scratch_bytes(cap)));
+        DVS_OR_THROW(dvs_mcmc_init_scratch(stream, d_mcmc, cap));
         reset_stats();
     }
     void reset_stats() {
@@ -125,6 +128,8 @@ struct GaussianTrainerScene::Impl {
         HIP_OR_THROW(hipMemsetAsync(d_max_radii, 0, (size_t)cap * 4, stream));
     }
     void densify(int it);
+    void densify_mcmc(int it);
+    bool mcmc() const { return cfg.densifyStrategy == 1; }
     dvs_splats splats() const {
         dvs_splats s{};
         s.pos = d_param[P_POS]; s.sh0 = d_param[P_SH0]; s.shN = d_param[P_SHN]; s.opacity = d_param[P_OPA];
@@ -235,7 +240,24 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     return true;
 }
 
-// clone / split / prune between two iterations (ADC; densifyStrategy 1 = MCMC in the reference is served by the same rule here)
+// densifyStrategy 1 (MCMC): dead splats are relocated onto live ones drawn ~ opacity, then the model grows by 5 % up to the cap.
+// In place: no second buffer set, no host round trip.
+void GaussianTrainerScene::Impl::densify_mcmc(int it) {
+    dvs_mcmc_sets sets{};
+    for (int g = 0; g < 6; ++g) { sets.param[g] = d_param[g]; sets.m[g] = d_m[g]; sets.v[g] = d_v[g]; }
+    DVS_OR_THROW(dvs_mcmc_relocate(stream, n, &sets, cfg.min_opacity, 2u * (uint32_t)it, DVS_SHN_TILED, d_mcmc, cap, nullptr));
+    const int target = std::min(cap, (int)(1.05 * (double)n));
+    const int n_new = target - n;
+    if (n_new > 0) {
+        DVS_OR_THROW(dvs_mcmc_grow(stream, n, n_new, &sets, cfg.min_opacity, 2u * (uint32_t)it + 1u, DVS_SHN_TILED, d_mcmc, cap));
+        if (cfg.verbose) logf_("mcmc @%d: %d -> %d splats", it, n, n + n_new);
+        n += n_new;
+        HIP_OR_THROW(hipMemsetAsync(d_grad[P_SHN], 0, dev_floats_for(P_SHN, cap) * sizeof(float), stream));   // pad lanes of the new last tile
+    }
+    host_valid = false;
+}
+
+// clone / split / prune between two iterations (densifyStrategy 0 ADC; 2 "ADC+" is served by the same rule)
 void GaussianTrainerScene::Impl::densify(int it) {
     dvs_densify_params prm{};
     prm.grad_threshold = cfg.growGrad2d;
@@ -336,8 +358,11 @@ void GaussianTrainerScene::trainStep() {
     g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
     g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = m.cfg.useAbsGrad ? m.d_absgrad : nullptr; g.mean2d = nullptr;
     DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
-    const bool refining = m.cfg.useAbsGrad && it < m.cfg.refineStopIter;
-    if (refining)      // densification statistics of this view
+    const bool mcmc = m.mcmc();
+    const bool refining = (mcmc || m.cfg.useAbsGrad) && it < m.cfg.refineStopIter;
+    if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule)
+        DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
+    if (refining && !mcmc)      // densification statistics of this view
         DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, m.d_absgrad, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
     // Adam, per-group learning rates (names gs_train.cpp:52-57; position lr decays exponentially init -> final)
     const float t = std::min(1.0f, (float)m.step / (float)std::max(1, m.cfg.numIters));
@@ -353,8 +378,11 @@ void GaussianTrainerScene::trainStep() {
     }
     if (deg == 0) ag[P_SHN].count = 0;
     DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, m.cfg.visibleAdam ? m.fwd.radii : nullptr, m.n));
-    if (refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0) m.densify(it);
-    if (refining && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0)
+    if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
+        DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
+                                        m.cfg.noiselr * lr_pos, (uint32_t)it));
+    if (refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0) { if (mcmc) m.densify_mcmc(it); else m.densify(it); }
+    if (refining && !mcmc && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0)
         DVS_OR_THROW(dvs_reset_opacity(m.stream, m.n, m.d_param[P_OPA], 0.01f, m.d_m[P_OPA], m.d_v[P_OPA]));
     if (m.cfg.verbose && (m.step % 100 == 0))          // same line the editor logs (application/editor/source/editor.cpp:1554)
         logf_("Iteraions %d, loss : %f", m.step, (double)getCurrentLoss());

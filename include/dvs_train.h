@@ -106,6 +106,29 @@ int dvs_densify_apply(void* stream, int n, const uint8_t* action, const uint32_t
 /* opacity reset (--resetAlphaEvery): opacity = min(opacity, logit(max_opacity)); zeroes the matching Adam moments if given. */
 int dvs_reset_opacity(void* stream, int n, float* opacity, float max_opacity, float* adam_m, float* adam_v);
 
+/* ---- MCMC densification strategy (--densifyStrategy 1, main.cpp:20,29; `noiselr` gs_train.cpp:97) ---------------------------------------
+ * The published rule the reference names ("3D Gaussian Splatting as Markov Chain Monte Carlo"); its own code is in the closed plugin.
+ * All arrays DEVICE, in A0 order (pos, sh0, shN, opacity, scale, rot), sized for `capacity` splats; m / v = Adam moments (entries may
+ * be NULL). Asynchronous on `stream`, no host round trip (the dead count is optional, read back asynchronously).
+ *   dvs_mcmc_relocate : every dead splat (sigmoid(opacity) <= min_opacity) becomes a copy of a live splat drawn with probability
+ *                       ~ opacity; a splat drawn c times and its c copies take opacity 1-(1-o)^(1/(c+1)) and the scale factor that
+ *                       preserves the rendered contribution; moments of everything touched are zeroed.
+ *   dvs_mcmc_grow     : n_new more copies drawn the same way are appended at [n, n+n_new) (caller: 5 % growth up to capMax).
+ *   dvs_mcmc_add_noise: after each optimizer step  pos += Sigma z gate(o) lr,  z ~ N(0,I), gate = sigmoid(-100 (o - 0.005));
+ *                       lr = noiselr * position learning rate.
+ *   dvs_mcmc_regularize: adds the gradients of  opacity_reg * mean(sigmoid(opacity)) + scale_reg * mean(exp(scale)).
+ * scratch: dvs_mcmc_scratch_bytes(capacity) bytes, zeroed once with dvs_mcmc_init_scratch (the draw counters live there). */
+typedef struct dvs_mcmc_sets { float* param[6]; float* m[6]; float* v[6]; } dvs_mcmc_sets;
+size_t dvs_mcmc_scratch_bytes(int capacity);
+int dvs_mcmc_init_scratch(void* stream, void* scratch, int capacity);
+int dvs_mcmc_relocate(void* stream, int n, const dvs_mcmc_sets* sets, float min_opacity, uint32_t seed, int shn_layout, void* scratch,
+                      int capacity, uint32_t* n_dead_out /* host (pinned), may be NULL */);
+int dvs_mcmc_grow(void* stream, int n, int n_new, const dvs_mcmc_sets* sets, float min_opacity, uint32_t seed, int shn_layout, void* scratch,
+                  int capacity);
+int dvs_mcmc_add_noise(void* stream, int n, float* pos, const float* scale, const float* rot, const float* opacity, float lr, uint32_t seed);
+int dvs_mcmc_regularize(void* stream, int n, const float* opacity, const float* scale, float* g_opacity, float* g_scale, float opacity_reg,
+                        float scale_reg);
+
 #ifdef __cplusplus
 }
 #endif

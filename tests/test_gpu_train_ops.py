@@ -227,3 +227,153 @@ def test_densify_plan_and_apply(gpu_device, tiled):
     torch.cuda.synchronize()
     np.testing.assert_allclose(op_d.cpu().numpy(), np.minimum(A["opacity"], np.log(0.01 / 0.99)), rtol=1e-6)
     assert not m.any() and not v.any()
+
+
+def _relocation_np(o, ratio, min_opacity):
+    """numpy restatement of the MCMC relocation rule (opacity / scale of the c+1 copies of a splat drawn c times)."""
+    from math import comb, sqrt
+    no = 1.0 - (1.0 - o) ** (1.0 / ratio)
+    denom = sum(comb(i - 1, k) * (-1) ** k * no ** (k + 1) / sqrt(k + 1) for i in range(1, ratio + 1) for k in range(i))
+    return min(max(no, min_opacity), 1.0 - 1.1920929e-7), o / denom
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_mcmc_relocate_grow(gpu_device, tiled):
+    """dvs_mcmc_relocate / dvs_mcmc_grow (densifyStrategy 1): dead splats become copies of live ones, growth appends copies, every
+    drawn splat and its copies carry the relocated opacity/scale of the published rule, moments of everything touched are zero,
+    untouched splats are bit-identical, and sources are drawn roughly in proportion to opacity."""
+    import ctypes as C
+    import torch
+    from divshot_amd._lib import lib, check, McmcSets
+    from divshot_amd.raster import shn_rows_to_tiled_np, shn_tiled_to_rows_np
+    rng = np.random.default_rng(11)
+    n, cap, n_new, min_op = 5000, 6000, 700, 0.005
+    widths = [3, 3, 45, 1, 3, 4]
+    P = [rng.standard_normal((n, w)).astype(np.float32) for w in widths]
+    P[3][:, 0] = rng.normal(0, 2.0, n)                        # logits
+    dead = rng.random(n) < 0.1
+    P[3][dead, 0] = -8.0                                      # sigmoid = 3e-4 < min_opacity
+    dead = 1.0 / (1.0 + np.exp(-P[3][:, 0].astype(np.float64))) <= min_op      # plus the few random logits below the threshold
+    P[4] = rng.normal(-3, 0.3, (n, 3)).astype(np.float32)
+
+    def to_dev(a, g):
+        full = np.zeros((cap, widths[g]), np.float32); full[:n] = a
+        if g == 2 and tiled:
+            return torch.tensor(shn_rows_to_tiled_np(full), device=gpu_device)
+        return torch.tensor(full.reshape(-1), device=gpu_device)
+
+    def to_host(t, g):
+        a = t.cpu().numpy()
+        return shn_tiled_to_rows_np(a, cap).reshape(cap, 45) if (g == 2 and tiled) else a.reshape(cap, widths[g])
+
+    par = [to_dev(P[g], g) for g in range(6)]
+    mom = [[torch.ones_like(par[g]) for g in range(6)] for _ in range(2)]
+    sets = McmcSets()
+    for g in range(6):
+        sets.param[g], sets.m[g], sets.v[g] = par[g].data_ptr(), mom[0][g].data_ptr(), mom[1][g].data_ptr()
+    scratch = torch.empty(int(lib.dvs_mcmc_scratch_bytes(cap)), dtype=torch.uint8, device=gpu_device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.dvs_mcmc_init_scratch(st, scratch.data_ptr(), cap))
+    n_dead = torch.zeros(1, dtype=torch.int32).pin_memory()
+    check(lib.dvs_mcmc_relocate(st, n, C.byref(sets), min_op, 7, int(tiled), scratch.data_ptr(), cap, n_dead.data_ptr()), "relocate")
+    torch.cuda.synchronize()
+    assert int(n_dead[0]) == int(dead.sum())
+    A = [to_host(par[g], g) for g in range(6)]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    o0 = sig(P[3][:, 0])
+
+    def check_copies(A, dst_rows, n_src, o_src, P_src):
+        """each destination row equals a live source row except opacity/scale; returns the source of each destination"""
+        key = {tuple(P_src[0][i]): i for i in range(n_src)}                   # positions are unique
+        srcs = np.array([key[tuple(A[0][d])] for d in dst_rows])
+        assert not (o_src[srcs] <= min_op).any()                              # only live splats are drawn
+        for g in (1, 2, 5):
+            np.testing.assert_array_equal(A[g][dst_rows], P_src[g][srcs])
+        return srcs
+
+    dst = np.nonzero(dead)[0]
+    srcs = check_copies(A, dst, n, o0, P)
+    cnt = np.bincount(srcs, minlength=n)
+    touched = np.zeros(n, bool); touched[dst] = True; touched[cnt > 0] = True
+    for i in np.nonzero(cnt > 0)[0][:200]:                                    # relocated opacity / scale of sources and of their copies
+        no, coeff = _relocation_np(float(o0[i]), int(cnt[i]) + 1, min_op)
+        rows = [i] + list(dst[srcs == i])
+        for r in rows:
+            assert abs(sig(A[3][r, 0]) - no) <= 2e-5 * max(no, 1e-3), (i, r)
+            np.testing.assert_allclose(A[4][r], P[4][i] + np.log(coeff), rtol=0, atol=3e-5)
+    for g in range(6):                                                        # untouched splats are bit-identical, moments of touched ones cleared
+        np.testing.assert_array_equal(A[g][:n][~touched], P[g][~touched])
+        for mm in mom:
+            M = to_host(mm[g], g)[:n]
+            assert (M[touched] == 0).all() and (M[~touched] == 1).all()
+    # sources ~ opacity: the mean opacity of the drawn splats is well above the mean opacity of the live ones
+    live = ~dead
+    assert o0[srcs].mean() > 1.15 * o0[live].mean()
+    # grow: appended copies at [n, n+n_new)
+    P1 = [a[:n].copy() for a in A]
+    o1 = sig(P1[3][:, 0])
+    for mm in mom:
+        for g in range(6):
+            mm[g].fill_(1.0)
+    check(lib.dvs_mcmc_grow(st, n, n_new, C.byref(sets), min_op, 8, int(tiled), scratch.data_ptr(), cap), "grow")
+    torch.cuda.synchronize()
+    B = [to_host(par[g], g) for g in range(6)]
+    new_rows = np.arange(n, n + n_new)
+    key = {}
+    for i in range(n):                                                        # relocated duplicates share a position: any of them is a valid source
+        key.setdefault(tuple(P1[0][i]), i)
+    srcs2 = np.array([key[tuple(B[0][d])] for d in new_rows])
+    for g in (1, 2, 5):
+        np.testing.assert_array_equal(B[g][new_rows], P1[g][srcs2])
+    assert (B[0][n + n_new:] == 0).all()
+    for mm in mom:
+        for g in range(6):
+            assert (to_host(mm[g], g)[new_rows] == 0).all()
+    # opacity mass is conserved in the sense of the rule: 1 - prod(1 - o') over the copies of a source == its old opacity
+    for i in np.unique(srcs2)[:100]:
+        same = [r for r in list(np.nonzero((P1[0] == P1[0][i]).all(1))[0])]
+        if len(same) > 1:
+            continue                                                          # ambiguous source (already a duplicate): skip
+        rows = [i] + list(new_rows[srcs2 == i])
+        o_after = sig(np.array([B[3][r, 0] for r in rows]))
+        assert abs((1 - np.prod(1 - o_after)) - o1[i]) <= 1e-4 * max(o1[i], 0.05) + (len(rows) * min_op if o_after.min() <= min_op * 1.01 else 0)
+
+
+def test_mcmc_noise_and_regularizer(gpu_device):
+    """dvs_mcmc_add_noise: displacement = Sigma z gate(o) lr (zero for solid splats, covariance-shaped for faint ones);
+    dvs_mcmc_regularize: gradients of opacity_reg mean(sigmoid) + scale_reg mean(exp)."""
+    import ctypes as C
+    import torch
+    from divshot_amd._lib import lib, check
+    n = 40000
+    rng = np.random.default_rng(2)
+    q = np.array([0.3, -0.5, 0.7, 0.2], np.float32)
+    logs = np.log(np.array([0.05, 0.2, 0.1], np.float32))
+    pos = np.zeros((n, 3), np.float32)
+    scale = np.tile(logs, (n, 1)); rot = np.tile(q, (n, 1))
+    opa = np.full(n, -9.0, np.float32); opa[n // 2:] = 2.0          # first half nearly dead (gate ~ 1), second half solid (gate ~ 0)
+    d = lambda a: torch.tensor(a, device=gpu_device)
+    dp, ds, dr, do = d(pos), d(scale), d(rot), d(opa)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lr = 0.5
+    check(lib.dvs_mcmc_add_noise(st, n, dp.data_ptr(), ds.data_ptr(), dr.data_ptr(), do.data_ptr(), lr, 3))
+    torch.cuda.synchronize()
+    disp = dp.cpu().numpy().astype(np.float64)
+    assert np.abs(disp[n // 2:]).max() < 1e-30                      # sigmoid(-100 (0.88 - 0.005)) underflows
+    qn = q / np.linalg.norm(q); w, x, y, z = qn
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    Sigma = R @ np.diag(np.exp(2 * logs.astype(np.float64))) @ R.T
+    o = 1 / (1 + np.exp(9.0)); gate = 1 / (1 + np.exp(100 * (o - 0.005)))
+    want = (gate * lr) ** 2 * Sigma @ Sigma.T
+    got = np.cov(disp[: n // 2].T, bias=True)
+    assert np.abs(disp[: n // 2].mean(0)).max() < 4 * np.sqrt(np.diag(want).max() / (n // 2))
+    np.testing.assert_allclose(got, want, rtol=0.08, atol=0.03 * np.abs(want).max())
+    # regulariser
+    go = torch.full((n,), 0.25, device=gpu_device); gs = torch.full((n, 3), -0.5, device=gpu_device)
+    check(lib.dvs_mcmc_regularize(st, n, do.data_ptr(), ds.data_ptr(), go.data_ptr(), gs.data_ptr(), 0.01, 0.02))
+    torch.cuda.synchronize()
+    so = 1 / (1 + np.exp(-opa.astype(np.float64)))
+    np.testing.assert_allclose(go.cpu().numpy(), 0.25 + 0.01 / n * so * (1 - so), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(gs.cpu().numpy(), -0.5 + 0.02 / (3 * n) * np.exp(scale.astype(np.float64)), rtol=1e-5, atol=1e-12)

@@ -95,7 +95,8 @@ def test_cli_densify_prune_reset(tmp_path):
     iterations, training keeps going, the checkpoint has the new count and can be resumed."""
     out = str(tmp_path / "m" / "iteration")
     cmd = [DRIVER, "--inputPath", "synthetic:N=30000,W=320,H=240,cams=6,sh=2,seed=5", "--maxIteration", "1000", "--outputPath", out,
-           "--warmupLength", "100", "--refineEvery", "100", "--resetAlphaEvery", "300", "--refineStopIter", "450", "--growGrad2d", "0.00005"]
+           "--warmupLength", "100", "--refineEvery", "100", "--resetAlphaEvery", "300", "--refineStopIter", "450", "--growGrad2d", "0.00005",
+           "--densifyStrategy", "0"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     steps = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"densify @(\d+): (\d+) -> (\d+) splats", p.stderr)]
@@ -112,3 +113,24 @@ def test_cli_densify_prune_reset(tmp_path):
     assert f"element vertex {final_n}" in head
     p2 = subprocess.run(cmd[:cmd.index("1000")] + ["1020"] + cmd[cmd.index("1000") + 1:] + ["--load_itr", "1000"], capture_output=True, text=True, timeout=600)
     assert p2.returncode == 0 and "(resumed)" in p2.stderr, p2.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_cli_mcmc_strategy(tmp_path):
+    """--densifyStrategy 1 (MCMC, the CLI default: main.cpp:20,29): relocation + 5 % growth per interval up to the cap,
+    exploration noise and the opacity/scale regularisers every step; training converges and the checkpoint has the new count."""
+    out = str(tmp_path / "m" / "iteration")
+    cmd = [DRIVER, "--inputPath", "synthetic:N=30000,W=320,H=240,cams=6,sh=2,seed=5", "--maxIteration", "800", "--outputPath", out,
+           "--warmupLength", "100", "--refineEvery", "100", "--refineStopIter", "450", "--densifyStrategy", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    steps = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"mcmc @(\d+): (\d+) -> (\d+) splats", p.stderr)]
+    assert [s_[0] for s_ in steps] == [200, 300, 400], p.stderr[-1500:]
+    n = 30000
+    for _, a, b in steps:
+        assert a == n and b == int(1.05 * a)
+        n = b
+    losses = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+|nan|inf)", p.stderr)]
+    assert len(losses) >= 7 and all(np.isfinite(losses)) and losses[-1] < 0.6 * losses[0], losses
+    head = open(out + "_800.ply", "rb").read(400).decode(errors="ignore")
+    assert f"element vertex {n}" in head
