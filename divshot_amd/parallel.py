@@ -123,3 +123,93 @@ class FactorisedExchange:
         centre of slot s (see slots())."""
         self.communicate(gbuf, group)
         rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree, shn_tiled=shn_tiled)
+
+
+class ShardedAdam:
+    """The optimizer half of the data-parallel step in its bandwidth-optimal form:
+        reduce-scatter(gradient rows)  ->  Adam on this rank's 1/G slice of the flat buffer  ->  all-gather(parameters).
+    Same wire volume as one all-reduce of the gradients, but the Adam work and its two moment arrays (472 B/splat) are divided
+    by G instead of being replicated. Parameters and gradients live in flat buffers in GradBuffer's order, so a rank's slice is
+    one contiguous range that may straddle parameter groups; Adam is element-wise, the per-group learning rates are applied to
+    the sub-ranges (dvs_adam_step_groups, one launch). Backends without reduce_scatter (gloo) fall back to all-reduce + slice.
+    """
+
+    def __init__(self, params_flat, group_sizes, lrs, world, rank, beta1=0.9, beta2=0.999, eps=1e-15, group=None):
+        """params_flat: flat fp32 tensor; group_sizes: floats per group in flat order; lrs: learning rate per group."""
+        assert sum(group_sizes) == params_flat.numel() and len(lrs) == len(group_sizes)
+        self.p, self.world, self.rank, self.group = params_flat, world, rank, group
+        self.betas, self.eps, self.lrs = (beta1, beta2), eps, list(lrs)
+        n = params_flat.numel()
+        self.shard = (n + world - 1) // world
+        self.shard = (self.shard + 3) & ~3                        # 16-B aligned slices
+        self.padded = self.shard * world
+        dev = params_flat.device
+        self.lo = min(n, rank * self.shard)
+        self.hi = min(n, self.lo + self.shard)
+        self.m = torch.zeros(self.shard, dtype=torch.float32, device=dev)      # moments only for the own slice
+        self.v = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.gshard = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.pshard = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self._gpad = torch.zeros(self.padded, dtype=torch.float32, device=dev) if self.padded != n else None
+        self._ppad = torch.zeros(self.padded, dtype=torch.float32, device=dev) if self.padded != n else None
+        # sub-ranges of the own slice per parameter group: (offset in slice, count, lr)
+        self.ranges, off = [], 0
+        for size, lr in zip(group_sizes, lrs):
+            a, b = max(off, self.lo), min(off + size, self.hi)
+            if b > a:
+                self.ranges.append((a - self.lo, b - a, lr))
+            off += size
+        self.step_no = 0
+
+    def _reduce_scatter(self, grads_flat):
+        import torch.distributed as dist
+        src = grads_flat
+        if self._gpad is not None:
+            self._gpad[: grads_flat.numel()].copy_(grads_flat)
+            src = self._gpad
+        if self.world == 1:
+            self.gshard.copy_(src[: self.shard])
+            return
+        try:
+            dist.reduce_scatter_tensor(self.gshard, src, op=dist.ReduceOp.SUM, group=self.group)
+        except (RuntimeError, NotImplementedError, ValueError):         # gloo: no reduce-scatter
+            dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.group)
+            self.gshard.copy_(src[self.rank * self.shard:(self.rank + 1) * self.shard])
+
+    def _adam(self, lr_scale=1.0):
+        b1, b2 = self.betas
+        t = self.step_no
+        if self.p.is_cuda:
+            from .train_ops import adam_step_groups
+            groups = [dict(param=self.pshard[o:o + c], grad=self.gshard[o:o + c], m=self.m[o:o + c], v=self.v[o:o + c], lr=lr * lr_scale, width=1)
+                      for o, c, lr in self.ranges]
+            for i in range(0, len(groups), 8):
+                adam_step_groups(groups[i:i + 8], t, b1, b2, self.eps)
+        else:                                                           # CPU tensors (gloo tests): the textbook recurrences in torch
+            for o, c, lr in self.ranges:
+                g = self.gshard[o:o + c]
+                self.m[o:o + c].mul_(b1).add_(g, alpha=1 - b1)
+                self.v[o:o + c].mul_(b2).addcmul_(g, g, value=1 - b2)
+                mh = self.m[o:o + c] / (1 - b1 ** t); vh = self.v[o:o + c] / (1 - b2 ** t)
+                self.pshard[o:o + c].sub_(lr * lr_scale * mh / (vh.sqrt() + self.eps))
+
+    def step(self, grads_flat, lr_scale=1.0):
+        """One optimizer step on every rank's replica: after it, params_flat holds the updated parameters everywhere."""
+        import torch.distributed as dist
+        self.step_no += 1
+        n = self.p.numel()
+        self._reduce_scatter(grads_flat)
+        self.pshard[: self.hi - self.lo].copy_(self.p[self.lo:self.hi])
+        self._adam(lr_scale)
+        if self.world == 1:
+            self.p.copy_(self.pshard[:n])
+            return
+        dst = self._ppad if self._ppad is not None else self.p
+        try:
+            dist.all_gather_into_tensor(dst, self.pshard, group=self.group)
+        except (RuntimeError, NotImplementedError, ValueError):
+            parts = [torch.empty_like(self.pshard) for _ in range(self.world)]
+            dist.all_gather(parts, self.pshard, group=self.group)
+            torch.cat(parts, out=dst)
+        if self._ppad is not None:
+            self.p.copy_(self._ppad[:n])

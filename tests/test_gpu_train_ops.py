@@ -377,3 +377,26 @@ def test_mcmc_noise_and_regularizer(gpu_device):
     so = 1 / (1 + np.exp(-opa.astype(np.float64)))
     np.testing.assert_allclose(go.cpu().numpy(), 0.25 + 0.01 / n * so * (1 - so), rtol=1e-5, atol=1e-12)
     np.testing.assert_allclose(gs.cpu().numpy(), -0.5 + 0.02 / (3 * n) * np.exp(scale.astype(np.float64)), rtol=1e-5, atol=1e-12)
+
+
+def test_sharded_adam_device_path(gpu_device):
+    """ShardedAdam's HIP path (one dvs_adam_step_groups launch over the sub-ranges of the slice) against the textbook recurrences;
+    world 1 here — the two-rank reduce-scatter / all-gather plumbing is covered by tests/test_parallel.py on gloo."""
+    import torch
+    from divshot_amd.parallel import ShardedAdam
+    n = 1001
+    sizes = [3 * n, 3 * n, 4 * n, n, 3 * n, 45 * n]
+    lrs = [1e-2, 5e-3, 1e-3, 5e-2, 2.5e-3, 1.25e-4]
+    total = sum(sizes)
+    rng = np.random.default_rng(4)
+    p0 = rng.standard_normal(total).astype(np.float32)
+    params = torch.tensor(p0, device=gpu_device)
+    opt = ShardedAdam(params, sizes, lrs, 1, 0, eps=1e-8)
+    ref = p0.astype(np.float64); m = np.zeros(total); v = np.zeros(total)
+    lr_vec = np.concatenate([np.full(s_, lr) for s_, lr in zip(sizes, lrs)])
+    for t in (1, 2, 3):
+        g = rng.standard_normal(total).astype(np.float32)
+        opt.step(torch.tensor(g, device=gpu_device))
+        m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g.astype(np.float64) ** 2
+        ref = ref - lr_vec * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
+    np.testing.assert_allclose(params.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)

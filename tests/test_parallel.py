@@ -111,3 +111,46 @@ def test_two_rank_gradient_allreduce_gloo():
         assert p.exitcode == 0
     sums = dict(out.get(timeout=5) for _ in range(world))
     assert abs(sums[0] - sums[1]) < 1e-3 * abs(sums[0])         # replicas hold identical reduced gradients
+
+
+def _worker_sharded_adam(rank, world, port, n, out):
+    sys.path.insert(0, ROOT)
+    from divshot_amd.parallel import ShardedAdam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [3 * n, 3 * n, 4 * n, n, 3 * n, 45 * n]                # flat order pos, scale, rot, opacity, sh0, shN
+    lrs = [1e-2, 5e-3, 1e-3, 5e-2, 2.5e-3, 1.25e-4]
+    total = sum(sizes)
+    g0 = torch.Generator().manual_seed(0)
+    p0 = torch.randn(total, generator=g0)
+    params = p0.clone()
+    opt = ShardedAdam(params, sizes, lrs, world, rank, eps=1e-8)
+    # reference: replicated Adam on the summed gradient
+    ref = p0.clone().double(); m = torch.zeros(total, dtype=torch.float64); v = torch.zeros(total, dtype=torch.float64)
+    lr_vec = torch.cat([torch.full((s_,), lr, dtype=torch.float64) for s_, lr in zip(sizes, lrs)])
+    for t in (1, 2, 3):
+        gs = [torch.randn(total, generator=torch.Generator().manual_seed(100 * t + r)) for r in range(world)]
+        opt.step(gs[rank].clone())
+        gsum = sum(g.double() for g in gs)
+        m = 0.9 * m + 0.1 * gsum; v = 0.999 * v + 0.001 * gsum * gsum
+        ref = ref - lr_vec * (m / (1 - 0.9 ** t)) / ((v / (1 - 0.999 ** t)).sqrt() + 1e-8)
+    assert torch.allclose(params.double(), ref, rtol=2e-5, atol=2e-6), float((params.double() - ref).abs().max())
+    assert opt.m.numel() <= (total + world - 1) // world + 4          # moments are sharded, not replicated
+    out.put((rank, float(params.sum())))
+    dist.destroy_process_group()
+
+
+def test_sharded_adam_gloo():
+    """reduce-scatter -> Adam on the own slice -> all-gather == replicated Adam on the summed gradient."""
+    world, n = 2, 37                                                # 59 * 37 = 2183 floats: slices straddle groups, padding exercised
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_adam, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sums = dict(out.get(timeout=5) for _ in range(world))
+    assert abs(sums[0] - sums[1]) < 1e-3                            # identical replicas after the all-gather
