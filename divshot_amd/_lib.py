@@ -35,8 +35,7 @@ class Opts(C.Structure):
 
 
 class FwdState(C.Structure):
-    _fields_ = [("radii", C.c_void_p), ("mean2d", C.c_void_p), ("depth", C.c_void_p), ("conic_opacity", C.c_void_p),
-                ("rgb", C.c_void_p), ("flags", C.c_void_p), ("tiles_touched", C.c_void_p), ("sorted_tile", C.c_void_p),
+    _fields_ = [("radii", C.c_void_p), ("splat2d", C.c_void_p), ("depth", C.c_void_p), ("flags", C.c_void_p), ("tiles_touched", C.c_void_p), ("sorted_tile", C.c_void_p),
                 ("sorted_splat", C.c_void_p), ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p),
                 ("num_rendered", C.c_uint64), ("n", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("_pad", C.c_int32)]

@@ -258,7 +258,7 @@ hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_id
 #define DUP_COOP_THRESHOLD 16
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ tiles_touched,
-            const uint32_t* __restrict__ block_offsets, const int* __restrict__ radii, const float2* __restrict__ mean2d,
+            const uint32_t* __restrict__ block_offsets, const float4* __restrict__ splat2d,
             int tiles_x, int tiles_y, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat) {
     __shared__ uint32_t tmp[SORT_WAVES + 1];
     const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
@@ -267,7 +267,11 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __re
     uint32_t tot;
     uint32_t off = block_excl_scan(touched, tmp, &tot) + block_offsets[blockIdx.x];
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
-    if (touched > 0) splat_rect(mean2d[id], radii[id], tiles_x, tiles_y, minx, miny, maxx, maxy);
+    if (touched > 0) {          // mean and radius come from the splat's 64-B record (one line per gather)
+        const float4 r0 = splat2d[4 * (size_t)id];
+        const int radius = __float_as_int(splat2d[4 * (size_t)id + 2].z);
+        splat_rect(make_float2(r0.x, r0.y), radius, tiles_x, tiles_y, minx, miny, maxx, maxy);
+    }
     const int w = maxx - minx;
     // small rects: the owning lane emits its tiles (row-major inside the rect)
     if (touched > 0 && touched <= DUP_COOP_THRESHOLD) {
@@ -295,12 +299,12 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __re
 }
 
 hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
-                                const uint32_t* block_offsets, const int* radii, const float* mean2d, int tiles_x,
+                                const uint32_t* block_offsets, const float* splat2d, int tiles_x,
                                 int tiles_y, uint32_t* inst_tile, uint32_t* inst_splat) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, tiles_touched, block_offsets, radii,
-                       (const float2*)mean2d, tiles_x, tiles_y, inst_tile, inst_splat);
+    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, tiles_touched, block_offsets,
+                       (const float4*)splat2d, tiles_x, tiles_y, inst_tile, inst_splat);
     return hipGetLastError();
 }
 

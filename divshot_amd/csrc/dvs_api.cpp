@@ -6,7 +6,7 @@
 // application/editor/source/editor.cpp:1620).
 //
 // HBM layout (all arenas are ctx-owned, grow-only, sized for max_splats / max image at create):
-//   per splat   : radii i32 | mean2d f32x2 | depth f32 | conic_opacity f32x4 | rgb f32x4 (r,g,b,0) | flags u32 |
+//   per splat   : radii i32 | splat2d 64-B record (mean, conic, opacity, rgb, depth, radius) | depth f32 | flags u32 |
 //                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 64 B/splat
 //   per instance: tile u32 x2 | splat u32 x2 (ping-pong)                                              = 16 B/instance
 //   per tile    : range u32x2          per pixel: final_T f32, n_contrib u32
@@ -64,7 +64,7 @@ struct dvs_ctx {
     int device = 0;
     size_t max_splats = 0;
     int max_w = 0, max_h = 0;
-    Buf radii, mean2d, depth, conic_opacity, rgb, flags, tiles_touched, key[2], ids[2], scan_blocks;
+    Buf radii, splat2d, depth, flags, tiles_touched, key[2], ids[2], scan_blocks;
     Buf inst_tile[2], inst_splat[2];
     Buf sort_scratch, tmp_keys, tmp_vals;
     Buf ranges, final_T, n_contrib;
@@ -113,7 +113,7 @@ void timing_collect(dvs_ctx* c, bool append) {
 int ensure_splat_arenas(dvs_ctx* c, size_t n) {
     int r;
 #define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
-    ENS(radii, n * 4) ENS(mean2d, n * 8) ENS(depth, n * 4) ENS(conic_opacity, n * 16) ENS(rgb, n * 16)
+    ENS(radii, n * 4) ENS(splat2d, n * 64) ENS(depth, n * 4)
     ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
     ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
     ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)
@@ -172,7 +172,7 @@ dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
 void dvs_destroy(dvs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    Buf* all[] = {&c->radii, &c->mean2d, &c->depth, &c->conic_opacity, &c->rgb, &c->flags, &c->tiles_touched, &c->key[0], &c->key[1],
+    Buf* all[] = {&c->radii, &c->splat2d, &c->depth, &c->flags, &c->tiles_touched, &c->key[0], &c->key[1],
                   &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
                   &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows};
     for (Buf* b : all) b->release();
@@ -205,8 +205,8 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     // A2 preprocess
     size_t e0 = tm.mark();
     HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree,
-                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->mean2d.as<float>(),
-                                       c->depth.as<float>(), c->conic_opacity.as<float>(), c->rgb.as<float>(),
+                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
+                                       c->depth.as<float>(),
                                        c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
                                        c->ids[0].as<uint32_t>(), opts->shn_layout));
     size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
@@ -231,7 +231,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     // A4 duplicate
     size_t e4 = tm.mark();
     HIPCHECK(dvs_launch_duplicate(st, n, c->ids[cur].as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
-                                  c->radii.as<int>(), c->mean2d.as<float>(), tiles_x, tiles_y, c->inst_tile[0].as<uint32_t>(),
+                                  c->splat2d.as<float>(), tiles_x, tiles_y, c->inst_tile[0].as<uint32_t>(),
                                   c->inst_splat[0].as<uint32_t>()));
     size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
     // A5 (high key bits): tile-id sort over instances
@@ -249,13 +249,13 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     // A7 composite
     HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
-                                   c->mean2d.as<float>(), c->conic_opacity.as<float>(), c->rgb.as<float>(), cam->bg, out_rgb,
+                                   c->splat2d.as<float>(), cam->bg, out_rgb,
                                    c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
     size_t e8 = tm.mark(); tm.span("render_fwd", e7, e8);
 
     dvs_fwd_state& s = c->st;
-    s.radii = c->radii.as<int32_t>(); s.mean2d = c->mean2d.as<float>(); s.depth = c->depth.as<float>();
-    s.conic_opacity = c->conic_opacity.as<float>(); s.rgb = c->rgb.as<float>(); s.flags = c->flags.as<uint32_t>();
+    s.radii = c->radii.as<int32_t>(); s.splat2d = c->splat2d.as<float>(); s.depth = c->depth.as<float>();
+    s.flags = c->flags.as<uint32_t>();
     s.tiles_touched = c->tiles_touched.as<uint32_t>();
     s.sorted_tile = c->inst_tile[icur].as<uint32_t>(); s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
     s.ranges = c->ranges.as<uint32_t>(); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
@@ -275,8 +275,8 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cam, cons
     c->rows_clean = false;
     size_t e1 = tm ? tm->mark() : 0;
     if (tm) tm->span("bwd_zero", e0, e1);
-    HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.mean2d, s.conic_opacity,
-                                   s.rgb, cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
+    HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
+                                   cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
     return DVS_OK;

@@ -7,8 +7,8 @@
 // preprocess.hip
 hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, const float* sh0, const float* shN,
                                      const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
-                                     int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* mean2d,
-                                     float* depth, float* conic_opacity, float* rgb, uint32_t* flags,
+                                     int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
+                                     float* depth, uint32_t* flags,
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
@@ -34,7 +34,7 @@ hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_id
                                 uint32_t* block_offsets, uint64_t* total_dev);
 // A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order.
 hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
-                                const uint32_t* block_offsets, const int* radii, const float* mean2d, int tiles_x,
+                                const uint32_t* block_offsets, const float* splat2d, int tiles_x,
                                 int tiles_y, uint32_t* inst_tile, uint32_t* inst_splat);
 // A6: per-tile [start,end) from the sorted tile ids.
 hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles);
@@ -44,10 +44,8 @@ hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* so
 
 // render.hip
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
-                                 const float* rgb, const float bg[3], float* out_color, float* final_T,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color, float* final_T,
                                  uint32_t* n_contrib);
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
-                                 const float* rgb, const float bg[3], const float* final_T, const uint32_t* n_contrib,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad);

@@ -76,15 +76,17 @@ struct __attribute__((aligned(16))) BatchLds {
 };
 
 __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt,
-                                            const float2* __restrict__ mean2d, const float4* __restrict__ conic_opacity,
-                                            const float4* __restrict__ rgb, float tile_x0, float tile_y0) {
+                                            const float4* __restrict__ splat2d, float tile_x0, float tile_y0) {
     const int t = threadIdx.x;
     uint32_t qm = 0;
     if (t < cnt) {
         const uint32_t id = sorted_splat[first + t];
-        const float2 xy = mean2d[id];
-        const float4 co = conic_opacity[id];
-        const float4 col = rgb[id];
+        // the splat's 64-B record (dvs_fwd_state.splat2d): three 16-B loads from ONE cache line
+        const float4 r0 = splat2d[4 * (size_t)id], r1 = splat2d[4 * (size_t)id + 1];
+        const float bl = splat2d[4 * (size_t)id + 2].x;
+        const float2 xy = make_float2(r0.x, r0.y);
+        const float4 co = make_float4(r0.z, r0.w, r1.x, r1.y);
+        const float3 col = make_float3(r1.z, r1.w, bl);
         L.xyc[t] = make_float4(xy.x, xy.y, -0.72134752044448170f * co.x, -1.4426950408889634f * co.y);
         L.zoir[t] = make_float4(-0.72134752044448170f * co.z, co.w, __uint_as_float(id), col.x);
         L.cog[t] = make_float4(co.x, co.y, co.z, col.y);
@@ -122,8 +124,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 // ---- A7 -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RB)
 k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ sorted_splat, const float2* __restrict__ mean2d,
-             const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb, float bg0, float bg1, float bg2,
+             const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     __shared__ BatchLds L;
     const int tile = tile_of_block(blockIdx.x, num_tiles);
@@ -143,7 +144,7 @@ k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
     for (int base = 0; base < total; base += RB) {
         if (__syncthreads_and(done)) break;
         const int cnt = min(RB, total - base);
-        stage_batch(L, sorted_splat, range.x + base, cnt, mean2d, conic_opacity, rgb, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
+        stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
         __syncthreads();
         if (__all(done)) continue;               // this wave's quadrant is finished
         // Predicated body (no per-lane branches: the scalar unit is shared by the CU's four SIMDs and a branchy
@@ -191,8 +192,7 @@ k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
 template <bool ABSGRAD>
 __global__ void __launch_bounds__(RB)
 k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ sorted_splat, const float2* __restrict__ mean2d,
-             const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb, float bg0, float bg1, float bg2,
+             const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
              const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
              float* __restrict__ grow /*[n,12]: mx my ca cb cc op r g b |mx| |my| pad*/) {
     __shared__ BatchLds L;
@@ -240,7 +240,7 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
         const int base = b * RB;
         const int cnt = min(RB, (int)todo - base);
         __syncthreads();
-        stage_batch(L, sorted_splat, range.x + base, cnt, mean2d, conic_opacity, rgb, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
+        stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
         __syncthreads();
 #pragma unroll 1
         for (int lw = RB / 64 - 1; lw >= 0; --lw) {
@@ -302,32 +302,30 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
 
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
-                                 const float* rgb, const float bg[3], float* out_color, float* final_T,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color, float* final_T,
                                  uint32_t* n_contrib) {
     const int num_tiles = tiles_x * tiles_y;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,
-                       (const float2*)mean2d, (const float4*)conic_opacity, (const float4*)rgb, bg[0], bg[1], bg[2], out_color, final_T,
+                       (const float4*)splat2d, bg[0], bg[1], bg[2], out_color, final_T,
                        n_contrib);
     return hipGetLastError();
 }
 
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* mean2d, const float* conic_opacity,
-                                 const float* rgb, const float bg[3], const float* final_T, const uint32_t* n_contrib,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows, int absgrad) {
     const int num_tiles = tiles_x * tiles_y;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     if (absgrad)
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges,
-                           sorted_splat, (const float2*)mean2d, (const float4*)conic_opacity, (const float4*)rgb, bg[0], bg[1], bg[2], final_T,
+                           sorted_splat, (const float4*)splat2d, bg[0], bg[1], bg[2], final_T,
                            n_contrib, dL_dout, grad_rows);
     else
         hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges,
-                           sorted_splat, (const float2*)mean2d, (const float4*)conic_opacity, (const float4*)rgb, bg[0], bg[1], bg[2], final_T,
+                           sorted_splat, (const float4*)splat2d, bg[0], bg[1], bg[2], final_T,
                            n_contrib, dL_dout, grad_rows);
     return hipGetLastError();
 }

@@ -184,10 +184,11 @@ class Rasterizer:
         s = self.state
         n, T, W, H = s.n, s.num_rendered, s.width, s.height
         tiles = s.tiles_x * s.tiles_y
+        rec = self._d2h(s.splat2d, (n, 16), np.float32)          # the packed 64-B record (DVS_S2D_* offsets)
         return {
-            "radii": self._d2h(s.radii, (n,), np.int32), "mean2d": self._d2h(s.mean2d, (n, 2), np.float32),
-            "depth": self._d2h(s.depth, (n,), np.float32), "conic_opacity": self._d2h(s.conic_opacity, (n, 4), np.float32),
-            "rgb": self._d2h(s.rgb, (n, 4), np.float32)[:, :3].copy(), "flags": self._d2h(s.flags, (n,), np.uint32),
+            "radii": self._d2h(s.radii, (n,), np.int32), "mean2d": rec[:, 0:2].copy(),
+            "depth": self._d2h(s.depth, (n,), np.float32), "conic_opacity": rec[:, 2:6].copy(),
+            "rgb": rec[:, 6:9].copy(), "splat2d": rec, "flags": self._d2h(s.flags, (n,), np.uint32),
             "tiles_touched": self._d2h(s.tiles_touched, (n,), np.uint32),
             "sorted_tile": self._d2h(s.sorted_tile, (T,), np.uint32), "vals": self._d2h(s.sorted_splat, (T,), np.uint32),
             "ranges": self._d2h(s.ranges, (tiles, 2), np.uint32), "final_T": self._d2h(s.final_T, (H, W), np.float32),

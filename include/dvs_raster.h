@@ -99,13 +99,15 @@ typedef struct dvs_opts {
 
 /* Saved forward state. DEVICE pointers into ctx-owned arenas; valid until the next
  * dvs_raster_forward on the same ctx. Exposed so the parity tests can diff every stage. */
+enum { DVS_S2D_X = 0, DVS_S2D_Y = 1, DVS_S2D_CONIC = 2, DVS_S2D_OPACITY = 5, DVS_S2D_RGB = 6, DVS_S2D_DEPTH = 9, DVS_S2D_RADIUS = 10,
+       DVS_S2D_FLOATS = 16 };
 typedef struct dvs_fwd_state {
     /* per splat (n) */
     const int32_t*  radii;          /* 0 = culled */
-    const float*    mean2d;         /* [n,2] pixel coords, pixel i centre = i */
-    const float*    depth;          /* [n] view-space z */
-    const float*    conic_opacity;  /* [n,4] conic a,b,c + final opacity */
-    const float*    rgb;            /* [n,4] clamped colour r,g,b + one pad float (16-B rows: one aligned load per gather) */
+    const float*    splat2d;        /* [n,16] the projected splat as ONE 64-byte record (one cache line per gather in A4/A7/A8):
+                                       DVS_S2D_X, _Y pixel coords of the mean (pixel i centre = i) | _CONIC a,b,c | _OPACITY final opacity |
+                                       _RGB clamped colour r,g,b | _DEPTH view-space z | _RADIUS (int32 bits) | 5 unused floats */
+    const float*    depth;          /* [n] view-space z (also the sort key) */
     const uint32_t* flags;          /* [n] bit0..2 = SH clamp (colour channel <0), bit3 = fx clamped, bit4 = fy clamped */
     const uint32_t* tiles_touched;  /* [n] */
     /* per instance (num_rendered), sorted by (tile, depth, splat id) */
