@@ -249,16 +249,19 @@ def main():
             achieved = ab[dom] / (single[dom] * 1e-3) / 1e9
             traffic, traffic_src = None, None
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01d_traffic.json")))
+                import glob
+                tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]      # the latest round's PMC passes
+                tj = json.load(open(tfile))
                 for kname, rec_ in tj["kernels"].items():
                     if kname.startswith("k_" + dom):
-                        traffic, traffic_src = rec_["hbm_bytes_per_launch_corrected"], "profiles/r01d_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KB->B)"
+                        traffic = rec_["hbm_bytes_per_launch_corrected"]
+                        traffic_src = "profiles/" + os.path.basename(tfile) + " (2*FETCH_SIZE + WRITE_SIZE, KB->B)"
             except Exception:
                 pass
             roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": single[dom],
-                        "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r01d_pmc_sq.txt), "
+                        "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r*_pmc_sq.txt), "
                                 "so its HBM fraction is low by construction; see DESIGN.md section 5"}
         stage_table = {}
         for k, v in stage_ms.items():

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Build profiles/rNN_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc.sh + rocpd_summary.py).
+usage: tools/make_traffic_json.py pmc_fetch.txt pmc_write.txt > profiles/rNN_traffic.json"""
+import json
+import re
+import sys
+
+
+def parse(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"\s+(\S.*?)\s+" + counter + r"\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
+        if m:
+            out[m.group(1).strip()] = float(m.group(3))
+    return out
+
+
+def main():
+    fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("k_"):
+            continue
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        kernels[k] = {"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
+                      "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+    how = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh) on bench.py's default workload, C3, "
+           "1x MI355X. Units are KB (x1024). Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE "
+           "reports half the bytes of wide coalesced reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibrated on "
+           "k_preprocess_fwd (236 B read per splat). The factor 2 is NOT calibrated for the narrow gathers of the composite kernels "
+           "(their figure is an upper bound), the counters include Infinity-Cache hits, and cross-XCD fp32 atomics are counted as writes.")
+    json.dump({"_how": how, "kernels": kernels}, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
