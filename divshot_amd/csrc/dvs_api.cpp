@@ -7,7 +7,7 @@
 //
 // HBM layout (all arenas are ctx-owned, grow-only, sized for max_splats / max image at create):
 //   per splat   : radii i32 | splat2d 64-B record (mean, conic, opacity, rgb, depth, radius) | depth f32 | flags u32 |
-//                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 64 B/splat
+//                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 96 B/splat
 //   per instance: tile u32 x2 | splat u32 x2 (ping-pong)                                              = 16 B/instance
 //   per tile    : range u32x2          per pixel: final_T f32, n_contrib u32
 //   backward    : one 48-B gradient row per splat: dL_d{mean2d x2, conic x3, opacity, rgb x3}, |dL_dmean2d| x2, pad
