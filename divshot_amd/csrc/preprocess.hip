@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(PP_BLOCK)
 k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
                  const float* __restrict__ scale, const float* __restrict__ rot, DvsCam cam, int deg, int antialias,
                  const int* __restrict__ radii, const uint32_t* __restrict__ flags,
-                 float4* __restrict__ grad_rows /*[n,3] float4: mx my ca cb | cc op r g | b |mx| |my| pad; re-zeroed here*/,
+                 float4* __restrict__ grad_rows /*[n,3] float4: Sx Sy Sxx Sxy | Syy So r g | b |mx| |my| pad (A8 moments); re-zeroed here*/,
                  float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
                  float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
                  float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor, int rezero) {
@@ -287,6 +287,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     float4* g4 = reinterpret_cast<float4*>(g_shN);
 
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    float2 dm_out = make_float2(0.f, 0.f);          // dL/dmean2D (optional output)
     if (radius > 0) {
         r0 = in_r0; r1 = in_r1; r2 = in_r2;
         // leave the accumulation row zeroed for the next backward (saves a 48 B/splat memset pass per view)
@@ -294,8 +295,6 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             grad_rows[3 * (int64_t)i] = z4; grad_rows[3 * (int64_t)i + 1] = z4; grad_rows[3 * (int64_t)i + 2] = z4;
         }
-        const float2 dL_dm = make_float2(r0.x, r0.y);
-        const float4 gco = make_float4(r0.z, r0.w, r1.x, r1.y);
         const float dL_dcol[3] = {r1.z, r1.w, r2.x};
         const float px = in_px, py = in_py, pz = in_pz;
         const uint32_t fl = in_fl;
@@ -338,6 +337,12 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float a = cxx + DVS_LOWPASS, b = cxy, c = cyy + DVS_LOWPASS;
         const float det = a * c - b * b;
         const float det_inv = 1.0f / det;
+        // A8 publishes moments of s = dL/dG * G about the mean (S_x S_y | S_xx S_xy S_yy | S_o); with the conic (A, B, C) — the same
+        // expressions, hence the same bits, as the forward wrote — they become the gradients of the 2D mean and of the conic
+        const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+        const float2 dL_dm = make_float2(-(cA * r0.x + cB * r0.y), -(cC * r0.y + cB * r0.x));
+        const float4 gco = make_float4(-0.5f * r0.z, -r0.w, -0.5f * r1.x, r1.y);
+        dm_out = dL_dm;
 
         // 1. colour / SH
         const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
@@ -515,7 +520,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
             out_absgrad2d[i] = a;
         }
         if (out_mean2d) {
-            float2 mm = make_float2(r0.x, r0.y);
+            float2 mm = dm_out;
             if (ACCUM) { const float2 o = out_mean2d[i]; mm.x += o.x; mm.y += o.y; }
             out_mean2d[i] = mm;
         }

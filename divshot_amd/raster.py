@@ -206,9 +206,14 @@ class Rasterizer:
         rows, width = C.c_void_p(), C.c_int(0)
         check(lib.dvs_get_bwd_intermediates(self.ctx, C.byref(rows), C.byref(width)))
         n = self.state.n
-        r = self._d2h(rows.value, (n, width.value), np.float32)
-        return {"dL_dmean2d": r[:, 0:2].copy(), "dL_dconic_opacity": r[:, 2:6].copy(), "dL_drgb": r[:, 6:9].copy(),
-                "absgrad": r[:, 9:11].copy()}
+        r = self._d2h(rows.value, (n, width.value), np.float32).astype(np.float64)
+        # A8 publishes moments about the mean; dvs_raster.h (dvs_get_bwd_intermediates) gives the conversion A9 applies
+        rec = self._d2h(self.state.splat2d, (n, 16), np.float32).astype(np.float64)
+        a, b, c = rec[:, 2], rec[:, 3], rec[:, 4]
+        dmean = np.stack([-(a * r[:, 0] + b * r[:, 1]), -(c * r[:, 1] + b * r[:, 0])], 1)
+        dconic = np.stack([-0.5 * r[:, 2], -r[:, 3], -0.5 * r[:, 4], r[:, 5]], 1)
+        return {"dL_dmean2d": dmean.astype(np.float32), "dL_dconic_opacity": dconic.astype(np.float32),
+                "dL_drgb": r[:, 6:9].astype(np.float32), "absgrad": r[:, 9:11].astype(np.float32)}
 
     def sort_pairs(self, keys, vals, bit_lo=0, bit_hi=32):
         """In-place stable LSD radix sort of CUDA uint32-as-int32 tensors."""

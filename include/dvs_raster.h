@@ -186,8 +186,11 @@ int dvs_sort_pairs_u32(dvs_ctx* ctx, void* stream, uint32_t* keys, uint32_t* val
  * DEVICE out_keys[T] (parity tests compare them bit-exactly with the oracle's stable_sort). */
 int dvs_export_sorted_keys(dvs_ctx* ctx, void* stream, uint64_t* out_keys);
 
-/* Intermediate gradients of the last backward (A8 output; DEVICE, ctx-owned): one row of *row_floats (=12) fp32 per
- * splat: dL/dmean2D x,y | dL/dconic a,b,c | dL/dopacity | dL/drgb r,g,b | sum|dL/dmean2D| x,y | pad — for stage-level parity. */
+/* Intermediate sums of the last backward (A8 output; DEVICE, ctx-owned): one row of *row_floats (=12) fp32 per splat:
+ *   S_x, S_y | S_xx, S_xy, S_yy | dL/dopacity | dL/drgb r,g,b | sum|dL/dmean2D| x,y | pad
+ * where S_* are the moments of s = dL/dG * G about the splat's 2D mean (d = mean - pixel). With the conic (a, b, c):
+ *   dL/dmean2D = -(a S_x + b S_y, c S_y + b S_x),   dL/dconic (a, b, c) = (-S_xx / 2, -S_xy, -S_yy / 2)
+ * (A9 applies this once per splat). For stage-level parity. */
 int dvs_get_bwd_intermediates(dvs_ctx* ctx, const float** rows, int* row_floats);
 /* By default the backward re-zeroes each row as A9 consumes it (no separate memset pass per view); keep = 1 leaves the rows
  * in place so dvs_get_bwd_intermediates() can be read after dvs_raster_backward (parity tests). */
