@@ -160,6 +160,9 @@ def main():
     if factorised:
         fx = FactorisedExchange(n, dev, world, views_per_rank=VPS)
         campos_all = np.array([list(dv.synth_camera(spec, (r * VPS + v) % n_cams).campos) for r, v in fx.slots()], np.float32)
+        # rebuild the SH rows of a view's slots right behind its all-gather, on the exchange's side stream
+        fx.set_combiner(lambda lo, hi, acc: rast.sh_grad_combine(params["pos"], campos_all[lo:hi], fx.dcolor_all[lo:hi], gbuf.views["sh0"],
+                                                                 gbuf.views["shN"], deg, accumulate=acc, shn_tiled=tiled))
     bwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
     step_done = torch.cuda.Event()
     main_stream = torch.cuda.current_stream(dev)

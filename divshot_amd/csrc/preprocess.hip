@@ -562,59 +562,92 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 // dL/dsh0 = SH_C0 * gc and dL/dshN[k] = basis_k(dir_v) * gc are rank-1 in the 3-float colour gradient gc of a view, so in
 // data-parallel training each GPU only has to all-gather gc (12 B/splat/view) instead of all-reducing the 192-B SH rows;
 // every replica then rebuilds the summed rows locally from its own copy of the positions and the views' camera centres.
-#define COMBINE_MAX_VIEWS 16
+#define COMBINE_MAX_VIEWS 64
 struct CombineViews { float campos[COMBINE_MAX_VIEWS][3]; };
 
 template <bool ACCUM, bool TILED>
 __global__ void __launch_bounds__(PP_BLOCK)
-k_sh_grad_combine(int n, const float* __restrict__ pos, int deg, int n_views, CombineViews views,
+k_sh_grad_combine(CombineViews views_arg /* MUST stay the first parameter: read through the kernarg pointer below */, int n,
+                  const float* __restrict__ pos, int deg, int n_views,
                   const float* __restrict__ dcolor /*[n_views, n, 3]*/, float* __restrict__ g_sh0, float* __restrict__ g_shN) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] + [PP_BLOCK*3]
+    // Indexing a by-value struct with a runtime view number makes the compiler spill the whole table to scratch (48 x 16-B
+    // scratch stores per lane, a scratch load per use). The table sits at offset 0 of the kernarg segment, which is uniform,
+    // read-only memory: address it directly (scalar loads with a dynamic offset).
+    (void)views_arg;
+    typedef const __attribute__((address_space(4))) CombineViews* KernargViews;
+    const KernargViews vp = (KernargViews)__builtin_amdgcn_kernarg_segment_ptr();
+#define views (*vp)
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // ROWS: [PP_BLOCK*45] + [PP_BLOCK*3]; TILED: [PP_BLOCK*3]
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
-    float* row = lds + threadIdx.x * 45;
-    float* l_sh0 = lds + PP_BLOCK * 45;
+    float* l_sh0 = TILED ? lds : lds + PP_BLOCK * 45;
     float acc0[3] = {0.f, 0.f, 0.f};
-    for (int e = 0; e < 45; ++e) row[e] = 0.f;
-    if (i < n) {
-        const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
-        const int ncoef = (deg + 1) * (deg + 1);
-        for (int v = 0; v < n_views; ++v) {
-            const float* gcp = dcolor + ((int64_t)v * n + i) * 3;
-            const float gc[3] = {gcp[0], gcp[1], gcp[2]};
-            if (gc[0] == 0.f && gc[1] == 0.f && gc[2] == 0.f) continue;          // culled / fully clamped in this view
-            const float dxw = px - views.campos[v][0], dyw = py - views.campos[v][1], dzw = pz - views.campos[v][2];
-            const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
-            const float inv_dl = 1.0f / dl;
-            float bas[16];
-            dvs_sh_basis(deg, dxw * inv_dl, dyw * inv_dl, dzw * inv_dl, bas);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) acc0[ch] += bas[0] * gc[ch];
-            for (int k = 1; k < ncoef; ++k)
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) row[(k - 1) * 3 + ch] += bas[k] * gc[ch];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) l_sh0[threadIdx.x * 3 + k] = acc0[k];
     if (TILED) {
+        // the 45 sums stay in registers (an LDS row per lane made this kernel LDS-bound: one read-modify-write per FMA), the
+        // k loop is fully unrolled (basis entries above `deg` are zero), and the twelve float4 chunks leave straight from registers
+        float acc[48];
+#pragma unroll
+        for (int e = 0; e < 48; ++e) acc[e] = 0.f;
         if (i < n) {
+            const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
+            for (int v = 0; v < n_views; ++v) {
+                const float* gcp = dcolor + ((int64_t)v * n + i) * 3;
+                const float gc[3] = {gcp[0], gcp[1], gcp[2]};
+                if (gc[0] == 0.f && gc[1] == 0.f && gc[2] == 0.f) continue;          // culled / fully clamped in this view
+                const float dxw = px - views.campos[v][0], dyw = py - views.campos[v][1], dzw = pz - views.campos[v][2];
+                const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+                const float inv_dl = 1.0f / dl;
+                float bas[16];
+                dvs_sh_basis(deg, dxw * inv_dl, dyw * inv_dl, dzw * inv_dl, bas);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) acc0[ch] += bas[0] * gc[ch];
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[(k - 1) * 3 + ch] += bas[k] * gc[ch];
+            }
             float4* d4 = reinterpret_cast<float4*>(g_shN);
 #pragma unroll
             for (int c = 0; c < 12; ++c) {
-                float4 o = c == 11 ? make_float4(row[44], 0.f, 0.f, 0.f)          // chunk 11 holds element 44 and three pads
-                                   : make_float4(row[c * 4], row[c * 4 + 1], row[c * 4 + 2], row[c * 4 + 3]);
+                float4 o = c == 11 ? make_float4(acc[44], 0.f, 0.f, 0.f)          // chunk 11 holds element 44 and three pads
+                                   : make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
                 const int64_t idx = shn_tiled_f4(i, c);
                 if (ACCUM) { const float4 p = d4[idx]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
                 d4[idx] = o;
             }
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l_sh0[threadIdx.x * 3 + k] = acc0[k];
         __syncthreads();
     } else {
+        float* row = lds + threadIdx.x * 45;
+        for (int e = 0; e < 45; ++e) row[e] = 0.f;
+        if (i < n) {
+            const float px = pos[3 * (int64_t)i], py = pos[3 * (int64_t)i + 1], pz = pos[3 * (int64_t)i + 2];
+            const int ncoef = (deg + 1) * (deg + 1);
+            for (int v = 0; v < n_views; ++v) {
+                const float* gcp = dcolor + ((int64_t)v * n + i) * 3;
+                const float gc[3] = {gcp[0], gcp[1], gcp[2]};
+                if (gc[0] == 0.f && gc[1] == 0.f && gc[2] == 0.f) continue;
+                const float dxw = px - views.campos[v][0], dyw = py - views.campos[v][1], dzw = pz - views.campos[v][2];
+                const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+                const float inv_dl = 1.0f / dl;
+                float bas[16];
+                dvs_sh_basis(deg, dxw * inv_dl, dyw * inv_dl, dzw * inv_dl, bas);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) acc0[ch] += bas[0] * gc[ch];
+                for (int k = 1; k < ncoef; ++k)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) row[(k - 1) * 3 + ch] += bas[k] * gc[ch];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l_sh0[threadIdx.x * 3 + k] = acc0[k];
         __syncthreads();
         stage_rows_out<45, ACCUM>(g_shN, lds, base, n);
     }
     stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
+#undef views
 }
 
 // ---- relayout between the reference rows [n][45] and the tiled layout --------------------------------------------------
@@ -698,14 +731,14 @@ hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, i
                                       const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled) {
     if (n <= 0 || n_views <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
-    const size_t lds = (size_t)PP_BLOCK * 48 * sizeof(float);
+    const size_t lds = (size_t)PP_BLOCK * (shn_tiled ? 3 : 48) * sizeof(float);
     int acc = accumulate;
-    for (int v0 = 0; v0 < n_views; v0 += COMBINE_MAX_VIEWS) {           // more than 16 views: chunks, accumulating
+    for (int v0 = 0; v0 < n_views; v0 += COMBINE_MAX_VIEWS) {           // more than 64 views: chunks, accumulating
         const int nv = n_views - v0 < COMBINE_MAX_VIEWS ? n_views - v0 : COMBINE_MAX_VIEWS;
         CombineViews cv;
         for (int v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) cv.campos[v][k] = campos_host[(size_t)(v0 + v) * 3 + k];
         const float* dc = dcolor + (size_t)v0 * n * 3;
-#define DVS_CMB(A, T) hipLaunchKernelGGL((k_sh_grad_combine<A, T>), dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, deg, nv, cv, dc, g_sh0, g_shN)
+#define DVS_CMB(A, T) hipLaunchKernelGGL((k_sh_grad_combine<A, T>), dim3(grid), dim3(PP_BLOCK), lds, st, cv, n, pos, deg, nv, dc, g_sh0, g_shN)
         if (acc) { if (shn_tiled) DVS_CMB(true, true); else DVS_CMB(true, false); }
         else { if (shn_tiled) DVS_CMB(false, true); else DVS_CMB(false, false); }
 #undef DVS_CMB

@@ -75,6 +75,14 @@ class FactorisedExchange:
         self.dcolor_all = torch.zeros((world * views_per_rank, n, 3), dtype=torch.float32, device=device)
         self._gathered = [False] * views_per_rank
         self._comm = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self._combiner = None
+        self._n_combined = 0
+
+    def set_combiner(self, fn):
+        """fn(slot_lo, slot_hi, accumulate): rebuild the SH rows of slots [slot_lo, slot_hi) (dvs_sh_grad_combine) — when set, the
+        rows of view v's slots are rebuilt right behind its all-gather on the side stream (nothing else writes the SH rows in
+        factorised mode), so only the last view's gather + rebuild stay exposed at the end of the step."""
+        self._combiner = fn
 
     def slots(self):
         """[(rank, local_view)] for every slot of dcolor_all, in order — index the per-view camera table with this."""
@@ -97,6 +105,9 @@ class FactorisedExchange:
         the last view's gather and the small geometry all-reduce stay exposed at the end of the step."""
         if self._comm is None:
             self._gather(v, group)
+            if self._combiner is not None:
+                self._combiner(v * self.world, (v + 1) * self.world, self._n_combined > 0)
+                self._n_combined += 1
         else:
             if ready is not None:
                 self._comm.wait_event(ready)
@@ -104,6 +115,9 @@ class FactorisedExchange:
                 self._comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm):
                 self._gather(v, group)
+                if self._combiner is not None:
+                    self._combiner(v * self.world, (v + 1) * self.world, self._n_combined > 0)
+                    self._n_combined += 1
         self._gathered[v] = True
 
     def communicate(self, gbuf, group=None):
@@ -113,6 +127,7 @@ class FactorisedExchange:
             if not self._gathered[v]:
                 self.gather_view(v, None, group)
         self._gathered = [False] * self.views_per_rank
+        self._n_combined = 0
         if self.world > 1:
             dist.all_reduce(gbuf.flat_geom, op=dist.ReduceOp.SUM, group=group)
         if self._comm is not None:
@@ -122,7 +137,8 @@ class FactorisedExchange:
         """Full exchange: after this, every view of gbuf holds the sum over all ranks' views. campos_all[s] is the camera
         centre of slot s (see slots())."""
         self.communicate(gbuf, group)
-        rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree, shn_tiled=shn_tiled)
+        if self._combiner is None:          # otherwise the rows were rebuilt slot by slot behind the gathers
+            rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree, shn_tiled=shn_tiled)
 
 
 class ShardedAdam:
