@@ -198,6 +198,17 @@ def main():
         elif dist is not None:
             dist.all_reduce(flat)
 
+    if factorised:
+        # The factorised exchange drives RCCL from a side stream; if this stack refuses that (API/driver differences between
+        # boxes), fall back to the plain all-reduce of the full rows instead of losing the measurement. Every rank sees the same error.
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            if rank == 0:
+                print(f"bench.py: factorised exchange failed ({type(e).__name__}: {e}); falling back to --exchange allreduce", file=sys.stderr)
+            factorised = False
+            exchange = "allreduce (fallback)"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
