@@ -48,7 +48,7 @@ class SplatGrads(C.Structure):
 
 class DensifyParams(C.Structure):
     _fields_ = [("grad_threshold", C.c_float), ("scale_threshold", C.c_float), ("min_opacity", C.c_float), ("max_world_scale", C.c_float),
-                ("max_screen_radius", C.c_int32), ("cap_max", C.c_int32), ("seed", C.c_uint32), ("shn_layout", C.c_int32)]
+                ("max_screen_radius", C.c_int32), ("cap_max", C.c_int32), ("seed", C.c_uint32), ("shn_layout", C.c_int32), ("revised_opacity", C.c_int32)]
 
 
 class AdamGroup(C.Structure):

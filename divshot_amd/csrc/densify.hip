@@ -151,7 +151,13 @@ k_densify_apply(int n, const uint8_t* __restrict__ action, const uint32_t* __res
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) d_rot[4 * (int64_t)j + k] = fresh ? 0.f : q[k];
-        d_op[j] = fresh ? 0.f : s_op[i];
+        float op = s_op[i];
+        if (mode == 0 && p.revised_opacity && a != DVS_DENSIFY_KEEP) {        // o' = 1 - sqrt(1 - o) for both results
+            const float o = 1.0f / (1.0f + __expf(-op));
+            const float no = fminf(fmaxf(1.0f - sqrtf(1.0f - o), 1e-6f), 1.0f - 1e-6f);
+            op = __logf(no / (1.0f - no));
+        }
+        d_op[j] = fresh ? 0.f : op;
         for (int e = 0; e < 45; ++e) d_shn[d_shn_index(p.shn_layout, j, e)] = fresh ? 0.f : s_shn[d_shn_index(p.shn_layout, i, e)];
     }
 }

@@ -264,9 +264,11 @@ void GaussianTrainerScene::Impl::densify(int it) {
     prm.scale_threshold = 0.01f * extent;                       // percent_dense x extent
     prm.min_opacity = cfg.min_opacity;
     const bool after_reset = it > cfg.resetAlphaEvery;
-    prm.max_world_scale = after_reset ? 0.1f * extent : 0.f;
-    prm.max_screen_radius = after_reset ? 20 : 0;
+    prm.max_world_scale = after_reset ? cfg.pruneScale3d * extent : 0.f;                     // `pruneScale3d` (fraction of the scene extent)
+    prm.max_screen_radius = after_reset && it < cfg.refineScale2dStopIter                    // `pruneScale2d` (fraction of the image size)
+                                ? std::max(1, (int)(cfg.pruneScale2d * (float)std::max(W, H))) : 0;
     prm.cap_max = cap; prm.seed = (uint32_t)it; prm.shn_layout = DVS_SHN_TILED;
+    prm.revised_opacity = cfg.revisedOpacity ? 1 : 0;
     uint64_t new_n = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         DVS_OR_THROW(dvs_densify_plan(stream, n, d_param[P_OPA], d_param[P_SCALE], d_grad_accum, d_denom, d_max_radii, &prm, d_action,
@@ -338,7 +340,7 @@ void GaussianTrainerScene::trainStep() {
     HIP_OR_THROW(hipSetDevice(m.device));
     // camera: xorshift over the view list (one view per iteration, as the reference's trainStep renders one camera)
     m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
-    const int ci = (int)(m.cam_rng % m.cams.size());
+    const int ci = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
     const int it = m.step + 1;
     const int deg = m.cfg.progressiveTrain ? std::min(m.sh_max, m.step / 1000) : m.sh_max;   // SH bands unlocked every 1000 steps
     dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0, DVS_SHN_TILED};

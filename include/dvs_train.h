@@ -92,6 +92,8 @@ typedef struct dvs_densify_params {
     int32_t cap_max;           /* hard cap on the new count */
     uint32_t seed;             /* RNG stream for split samples (use the step number) */
     int32_t shn_layout;        /* DVS_SHN_ROWS / DVS_SHN_TILED for the shN arrays passed to dvs_densify_apply */
+    int32_t revised_opacity;   /* config `revisedOpacity`: both results of a clone / split take opacity 1 - sqrt(1 - o), so that
+                                  the pair composites to the opacity of the splat it replaces ("Revising Densification in GS") */
 } dvs_densify_params;
 
 int dvs_densify_accumulate(void* stream, int n, const int32_t* radii, const float* absgrad2d, int width, int height,

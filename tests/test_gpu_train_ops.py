@@ -221,6 +221,22 @@ def test_densify_plan_and_apply(gpu_device, tiled):
         else:
             assert np.array_equal(pos[o[keep]], A["pos"][keep]) and np.array_equal(pos[o[clone]], A["pos"][clone])
             assert not pos[o[clone] + 1].any() and not pos[o[split]].any() and not pos[o[split] + 1].any() and not shn[o[split]].any()
+    # config `revisedOpacity`: both results of a clone / split take 1 - sqrt(1 - o); kept splats are untouched
+    prm.revised_opacity = 1
+    dst = [torch.zeros(new_n * 3, device=dev), torch.zeros(new_n * 3, device=dev), torch.zeros(shn_new, device=dev),
+           torch.zeros(new_n, device=dev), torch.zeros(new_n * 3, device=dev), torch.zeros(new_n * 4, device=dev)]
+    dp = (C.c_void_p * 6)(*[x.data_ptr() for x in dst])
+    check(lib.dvs_densify_apply(st, n, action.data_ptr(), offs.data_ptr(), C.byref(prm), 0, sp, dp, new_n))
+    torch.cuda.synchronize()
+    op = dst[3].cpu().numpy().astype(np.float64)
+    assert np.array_equal(dst[3].cpu().numpy()[o[keep]], A["opacity"][keep])
+    for idx in (clone, split):
+        want_o = 1.0 - np.sqrt(1.0 - sig[idx])
+        for c in (0, 1):
+            got_o = 1 / (1 + np.exp(-op[o[idx] + c]))
+            np.testing.assert_allclose(got_o, np.clip(want_o, 1e-6, 1 - 1e-6), rtol=2e-4, atol=1e-7)
+            # the pair composites to the opacity it replaces: 1 - (1 - o')^2 = o
+        np.testing.assert_allclose(1 - (1 - 1 / (1 + np.exp(-op[o[idx]]))) ** 2, sig[idx], rtol=5e-4, atol=2e-6)
     # opacity reset
     m, v = torch.ones(n, device=dev), torch.ones(n, device=dev)
     check(lib.dvs_reset_opacity(st, n, op_d.data_ptr(), 0.01, m.data_ptr(), v.data_ptr()))
