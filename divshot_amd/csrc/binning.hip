@@ -64,11 +64,19 @@ k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t d
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr int SORT_PART = SORT_BLOCK * SORT_ITEMS;
     const uint64_t wbase = (uint64_t)blockIdx.x * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
+    // all of the lane's keys are requested before the first one is used: with one load per round the kernel is bound by
+    // SORT_ITEMS dependent HBM round trips at 3 waves per SIMD
+    uint32_t kreg[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+        kreg[r] = idx < n ? keys[idx] : 0u;
+    }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = valid ? ((keys[idx] >> shift) & dmask) : 0u;
+        const uint32_t d = valid ? ((kreg[r] >> shift) & dmask) : 0u;
         const uint64_t peers = match_digit(d, valid);
         if (valid) {
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
