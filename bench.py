@@ -3,7 +3,7 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
-A step = one pass of the hot path over one batch: every rank renders --views-per-step (default 4) independent synthetic
+A step = one pass of the hot path over one batch: every rank renders --views-per-step (default 8 = the "8 synthetic cams/iter" of BASELINE config C4) independent synthetic
 views of the replicated 1M-splat scene (A2..A7), forms dL/drgb = (rgb - target)/P and runs the backward (A8, A9) for each,
 accumulating the gradient rows; the views of a step are software-pipelined over two rasterizer contexts / HIP streams
 (steps do not overlap). For N>1 the step ends by exchanging the 59-float gradient rows over xGMI: by default the factorised exchange of
@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=2, help="rasterizer contexts / HIP streams the views of a step are pipelined over")
     ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
                     help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
-                         "12 B per splat per view, SH rows rebuilt locally); auto picks the one that puts fewer bytes on the wire")
-    ap.add_argument("--views-per-step", type=int, default=4,
+                         "12 B per splat per view, SH rows rebuilt locally, gathers overlapped with compute); auto = factorised")
+    ap.add_argument("--views-per-step", type=int, default=8,
                     help="independent views each GPU renders per step (pipelined over two contexts when > 1); gradients accumulate")
     ap.add_argument("--shn-tiled", type=int, default=1,
                     help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
