@@ -303,6 +303,20 @@ def main():
                          "frac_of_hbm_peak_end_to_end": total_bytes * VPS / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
                          "sum_of_stage_ms": raster_ms, "stages": stage_table},
         }
+        # compute-side figure of SURVEY.md §8(d): pixel-splat interactions I = sum over tiles of (list entries walked before all 256
+        # pixels of the tile terminate) x 256, from the saved n_contrib of the last profiled view
+        try:
+            nc = torch.from_numpy(rast._d2h(st.n_contrib, (H, W), np.uint32).astype(np.int64))
+            ty_, tx_ = st.tiles_y, st.tiles_x
+            pad = torch.zeros((ty_ * 16, tx_ * 16), dtype=torch.int64); pad[:H, :W] = nc
+            per_tile = pad.view(ty_, 16, tx_, 16).permute(0, 2, 1, 3).reshape(ty_ * tx_, 256).max(dim=1).values
+            inter = int(per_tile.sum()) * 256
+            rec["interactions"] = {"I_per_view": inter, "mean_list_entries_walked_per_tile": float(per_tile.double().mean()),
+                                   "fwd_per_s": inter / (stage_ms["render_fwd"] * 1e-3) if "render_fwd" in stage_ms else None,
+                                   "bwd_per_s": inter / (stage_ms["render_bwd"] * 1e-3) if "render_bwd" in stage_ms else None,
+                                   "note": "upper bound on evaluated pairs: per-8x8-quadrant culling skips ~2/3 of them (DESIGN.md section 5)"}
+        except Exception as e:      # noqa: BLE001
+            rec["interactions"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 rec["cpu_baseline"] = cpu_baseline(args.workload)

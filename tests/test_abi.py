@@ -36,11 +36,14 @@ def test_struct_layout_matches_c():
 #include <stddef.h>
 #include "dvs_raster.h"
 #include "dvs_scene.h"
+#include "dvs_train.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(dvs_splats), sizeof(dvs_camera), sizeof(dvs_opts), sizeof(dvs_fwd_state),
          sizeof(dvs_splat_grads), sizeof(dvs_scene_spec));
   printf("%zu %zu %zu %zu\n", offsetof(dvs_camera, campos), offsetof(dvs_camera, bg), offsetof(dvs_fwd_state, num_rendered),
          offsetof(dvs_scene_spec, seed));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(dvs_adam_group), sizeof(dvs_densify_params), sizeof(dvs_mcmc_sets),
+         offsetof(dvs_adam_group, lr), offsetof(dvs_densify_params, revised_opacity));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
@@ -51,8 +54,11 @@ int main(void) {
     sizes = [int(v) for v in out[:6]]
     assert sizes == [C.sizeof(_lib.Splats), C.sizeof(_lib.Camera), C.sizeof(_lib.Opts), C.sizeof(_lib.FwdState),
                      C.sizeof(_lib.SplatGrads), C.sizeof(_lib.SceneSpec)]
-    offs = [int(v) for v in out[6:]]
+    offs = [int(v) for v in out[6:10]]
     assert offs == [_lib.Camera.campos.offset, _lib.Camera.bg.offset, _lib.FwdState.num_rendered.offset, _lib.SceneSpec.seed.offset]
+    train = [int(v) for v in out[10:]]           # the structs of include/dvs_train.h
+    assert train == [C.sizeof(_lib.AdamGroup), C.sizeof(_lib.DensifyParams), C.sizeof(_lib.McmcSets), _lib.AdamGroup.lr.offset,
+                     _lib.DensifyParams.revised_opacity.offset]
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
