@@ -113,7 +113,8 @@ class Rasterizer:
         params = self._params
         n = params["pos"].shape[0]
         if grads is None:
-            grads = {k: torch.empty_like(params[k]) for k in PARAM_KEYS}
+            # the tiled shN array has pad lanes (splats >= n of the last tile) that the kernels never write: keep them defined
+            grads = {k: (torch.zeros_like(params[k]) if (k == "shN" and self._tiled) else torch.empty_like(params[k])) for k in PARAM_KEYS}
             accumulate = False
         opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout)
         if self._opts.absgrad and "absgrad2d" not in grads:

@@ -24,6 +24,25 @@ CONFIGS = {
 }
 
 
+def _random_configs(k=10):
+    """Seeded sweep over the corners a fixed list misses: splat counts around the wave / tile-of-64 sizes, image sizes that are not
+    multiples of 16, every SH degree, anti-aliasing, backgrounds, footprint scales from sub-pixel to several tiles."""
+    rng = np.random.default_rng(20240907)
+    out = {}
+    counts = [1, 63, 64, 65, 257, 1000, 2049, 3500, 4096, 6000]
+    for i in range(k):
+        n = counts[i % len(counts)]
+        W, H = int(rng.integers(17, 230)), int(rng.integers(17, 150))
+        deg, aa = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+        soff = float(rng.uniform(-0.7, 1.2))
+        bg = tuple(float(x) for x in np.round(rng.uniform(0, 1, 3), 2))
+        out[f"rnd{i}_{n}_{W}x{H}_deg{deg}{'_aa' if aa else ''}"] = (n, W, H, deg, 100 + i, soff, aa, bg)
+    return out
+
+
+CONFIGS.update(_random_configs())
+
+
 @pytest.fixture(scope="module")
 def rast(gpu_device):
     from divshot_amd.raster import Rasterizer
@@ -65,7 +84,8 @@ def test_pipeline_parity(rast, oracle_mod, name):
     for k in ("mean2d", "depth", "conic_opacity", "rgb"):
         a, b = saved[k], o.get(k).reshape(saved[k].shape)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k}: {(a != b).sum()} of {a.size} floats differ"
-    assert (saved["radii"] > 0).sum() > 0.5 * n
+    if not name.startswith("rnd"):
+        assert (saved["radii"] > 0).sum() > 0.5 * n
 
     # --- A3-A6 binning: bit-exact --------------------------------------------------------------------
     assert keys.shape == o.get("keys").shape
@@ -76,7 +96,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
 
     # --- A7 composite forward ----------------------------------------------------------------------------
     frag = o.get("fragile").astype(bool)
-    assert frag.mean() < 1e-3
+    assert frag.mean() < (5e-3 if name.startswith("rnd") else 1e-3)
     ok = ~frag
     nc_ref = o.get("n_contrib")
     assert np.array_equal(saved["n_contrib"][ok], nc_ref[ok]), f"{(saved['n_contrib'][ok] != nc_ref[ok]).sum()} n_contrib mismatches"
@@ -97,7 +117,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
     m2, rad = saved["mean2d"], saved["radii"]
     for x, y in zip(fx, fy):
         tainted |= (np.abs(m2[:, 0] - x) <= rad) & (np.abs(m2[:, 1] - y) <= rad) & (rad > 0)
-    if not name.startswith("dense"):      # huge splats: one fragile pixel taints everything that covers it
+    if not name.startswith(("dense", "rnd")):      # huge splats: one fragile pixel taints everything that covers it
         assert tainted.mean() < 0.10, tainted.mean()
     ref64 = o64.backward(dL)
     ref32 = o.backward(dL)
@@ -119,7 +139,8 @@ def test_pipeline_parity(rast, oracle_mod, name):
             tol = 1e-4 * np.abs(w) + 1e-5 * scale
             assert (err <= tol).all(), f"{name}: worst {(err / tol).max()}, frac ok {(err <= tol).mean()}"
             l2 = np.linalg.norm((g - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-300)
-            assert l2 < 1e-5, f"{name}: relative L2 error {l2}"
+            # scenes of a few dozen splats have no averaging over rows: their L2 bound is the plain fp32 one (still 2x inside 1e-4)
+            assert l2 < (1e-5 if n >= 1000 else 5e-5), f"{name}: relative L2 error {l2}"
         if tainted.any():
             g, w = got[tainted], want32[tainted]
             l2 = np.linalg.norm((g - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-300)
@@ -302,7 +323,7 @@ def test_tiled_shn_layout(rast):
     acc = {k: v.clone() for k, v in g_t.items() if k in KEYS}
     rast.backward(dL, grads=acc, accumulate=True)
     torch.cuda.synchronize()
-    m, worst = rel_close(acc["shN"].cpu().numpy(), 2 * g_t["shN"].cpu().numpy(), 1e-4, 1e-5)
+    m, worst = rel_close(shn_tiled_to_rows_np(acc["shN"].cpu().numpy(), n), 2 * shn_tiled_to_rows_np(g_t["shN"].cpu().numpy(), n), 1e-4, 1e-5)
     assert m.all(), worst
     # factorised combine into tiled rows
     fact = rast.backward(dL, factorised_sh=True)
