@@ -396,6 +396,15 @@ def test_edge_cases(rast, oracle_mod):
     r = saved["ranges"]
     assert (r[:, 1] - r[:, 0]).max() > 256
     assert (saved["final_T"] < 2e-4).any()
+    # depth keys that span 17 binades (depths from 0.25 to 30 000): every byte of the 32-bit depth key carries order information;
+    # the order is still the oracle's stable sort, bit for bit
+    n = 3000
+    P = mk(n); z = np.exp(rng.uniform(np.log(0.25), np.log(3.0e4), n)).astype(np.float32); P["pos"][:, 2] = z
+    P["pos"][:, 0] = (rng.uniform(-0.3, 0.3, n) * z).astype(np.float32); P["pos"][:, 1] = (rng.uniform(-0.15, 0.15, n) * z).astype(np.float32)
+    P["scale"][:] = np.log(1.5 * z / fx)[:, None].astype(np.float32); P["opacity"][:] = 0.0; P["sh0"][:] = rng.normal(0, 1, (n, 3))
+    img, saved, o = run(P)
+    dk = saved["depth"][saved["radii"] > 0].view(np.uint32)
+    assert int(dk.max()) - int(np.float32(0.2).view(np.uint32)) >= 1 << 27 and (saved["radii"] > 0).sum() > 2000
     # a tile list with more than 65 536 entries (SURVEY.md §8(c) edge fixture): 70k faint 1-px splats over one tile; alpha only
     # just clears 1/255 near each centre, so no pixel saturates and every wave walks the whole list (274 LDS batches)
     n = 70_000
