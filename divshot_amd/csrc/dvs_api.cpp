@@ -10,7 +10,8 @@
 //                 tiles_touched u32 | depth_key u32 x2 (ping-pong) | ids u32 x2 (ping-pong)          = 96 B/splat
 //   per instance: tile u32 x2 | splat u32 x2 (ping-pong)                                              = 16 B/instance
 //   per tile    : range u32x2          per pixel: final_T f32, n_contrib u32
-//   backward    : one 48-B gradient row per splat: dL_d{mean2d x2, conic x3, opacity, rgb x3}, |dL_dmean2d| x2, pad
+//   backward    : one 48-B row per splat: moments S_x S_y S_xx S_xy S_yy of dL/dG*G about the mean (A9 turns them into
+//                 dL/dmean2D and dL/dconic), dL/dopacity, dL/drgb x3, |dL/dmean2D| x2, pad
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
