@@ -272,9 +272,32 @@ def main():
                         traffic_src = "profiles/" + os.path.basename(tfile) + " (2*FETCH_SIZE + WRITE_SIZE, KB->B)"
             except Exception:
                 pass
+            # VALU issue occupancy of the same kernel from the committed SQ counter pass (its own rocprofv3 run): SQ_ACTIVE_INST_VALU
+            # counts 4-cycle quads per SIMD, so quads * 4 / (SIMDs * duration * clock) is the fraction of the kernel's duration the
+            # vector ALUs were issuing. It is ~1.0 for k_render_bwd: the kernel is VALU-bound, which is why its HBM fraction is low.
+            valu = None
+            try:
+                import glob, re
+                sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")))[-1]
+                dur_us = act = insts = None
+                for line in open(sq):
+                    if not line.lstrip().startswith("k_" + dom):
+                        continue
+                    f = line.split()
+                    if "SQ_ACTIVE_INST_VALU" in f:
+                        act = float(f[-1])
+                    elif "SQ_INSTS_VALU" in f:
+                        insts = float(f[-1])
+                    elif dur_us is None and len(f) > 6 and re.fullmatch(r"[0-9.]+", f[-10] or ""):
+                        dur_us = float(f[-10])          # avg_us column of the kernel-trace table
+                if dur_us and act:
+                    valu = {"source": "profiles/" + os.path.basename(sq), "insts_valu_per_launch": insts, "active_quads_per_launch": act,
+                            "avg_us_under_pmc": dur_us, "busy_fraction_at_2.4GHz": act * 4.0 / (1024 * dur_us * 1e-6 * 2.4e9)}
+            except Exception:
+                pass
             roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": single[dom],
+                        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": single[dom], "valu_issue": valu,
                         "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r*_pmc_sq.txt), "
                                 "so its HBM fraction is low by construction; see DESIGN.md section 5"}
         stage_table = {}
