@@ -70,11 +70,16 @@ def cpu_baseline(workload, max_seconds=60.0):
     else:
         spec = dv.make_spec(n, W, H, sh_degree=deg, scale_log_offset=soff)
         P = dv.synth_splats(spec); cam = dv.synth_camera(spec, 0); tgt = dv.synth_target(spec, 0)
-        t0 = time.perf_counter(); img = o.forward(P, cam, sh_degree=deg); o.backward((img - tgt) / tgt[0].size)
+        t0 = time.perf_counter(); img = o.forward(P, cam, sh_degree=deg); ref_grads = o.backward((img - tgt) / tgt[0].size)
         secs = time.perf_counter() - t0
         sample = f"{workload} full ({n} splats, {W}x{H}, SH{deg}), 1 view fwd+bwd, OpenMP {cores} threads"
+        cpu_baseline.reference = {"img": img, "grads": ref_grads, "fragile": o.get("fragile").astype(bool),
+                                  "num_rendered": int(o.get("vals").size)}          # the checker's outputs for view 0 (parity_vs_oracle)
     return {"value": 1.0 / secs, "unit": "views/s (of the sample)", "cores": cores, "kind": "port",
             "sample": sample, "seconds": secs, "sample_fraction_of_splats": frac}
+
+
+cpu_baseline.reference = None
 
 
 def main():
@@ -228,6 +233,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
+                                                                                   # (taken before the profiling iterations reuse the buffer)
     # ---- per-stage hipEvent timing (separate iterations; timing mode synchronises per call) --------------
     stage_ms = {}
     if rank == 0 and args.profile_iters > 0:
@@ -244,7 +251,6 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
     if rank == 0:
         st = rast.state
         V = int((torch.from_numpy(rast._d2h(st.radii, (n,), np.int32)) > 0).sum())
@@ -345,6 +351,24 @@ def main():
                 rec["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:      # the oracle is test infrastructure; its absence must not hide the GPU number
                 rec["cpu_baseline"] = {"error": repr(e)}
+            # the oracle just computed view 0 at full size: use it as the checker of the HIP path's view 0 (same splats, camera, target)
+            ref = cpu_baseline.reference
+            if ref is not None:
+                try:
+                    img_g = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
+                    g1 = rast.backward(((img_g - target) * inv_P).contiguous())
+                    torch.cuda.synchronize()
+                    ok = ~ref["fragile"]
+                    ih = img_g.cpu().numpy()
+                    err = np.abs(ih[:, ok] - ref["img"][:, ok]) / (1e-4 * np.abs(ref["img"][:, ok]) + 1e-6)
+                    par = {"view": 0, "num_rendered_equal": int(rast.num_rendered) == ref["num_rendered"],
+                           "rgb_max_err_over_tol(1e-4 rel + 1e-6)": float(err.max()), "fragile_pixels": int(ref["fragile"].sum())}
+                    for k_ in ("pos", "sh0", "opacity", "scale", "rot"):
+                        a, b = g1[k_].double().cpu().numpy(), np.asarray(ref["grads"][k_], np.float64)
+                        par["grad_rel_l2_" + k_] = float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+                    rec["parity_vs_oracle"] = par
+                except Exception as e:      # noqa: BLE001
+                    rec["parity_vs_oracle"] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)
     for r_ in rasts:
         r_.close()

@@ -1,5 +1,5 @@
 """Full-size configs on the GPU (BASELINE.json C3 and the C5 stress shape) checked through size-independent properties
-(the oracle is too slow to run at these sizes inside the GPU suite; C3 parity against the oracle is in tools/gpu_diag.py):
+(the oracle is too slow to run at these sizes inside the GPU suite; C3 parity against the oracle: tests/diag_gpu_vs_oracle.py and the `parity_vs_oracle` field of bench.py):
   * per-tile lists are sorted by (depth, splat id) and ranges tile the instance list exactly,
   * sum(tiles_touched) == T, every instance's tile lies inside its splat's rect,
   * compositing invariants: 0 <= final_T <= 1, n_contrib <= list length, image finite,
