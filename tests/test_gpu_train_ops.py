@@ -416,3 +416,59 @@ def test_sharded_adam_device_path(gpu_device):
         m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g.astype(np.float64) ** 2
         ref = ref - lr_vec * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-8)
     np.testing.assert_allclose(params.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+
+
+def test_mcmc_edge_cases(gpu_device):
+    """dvs_mcmc_relocate / dvs_mcmc_grow at the corners: no dead splat (no-op), every splat dead (nothing to draw from: no-op),
+    zero growth, a single live splat drawn for every new slot (the ratio saturates at 51)."""
+    import ctypes as C
+    import torch
+    from divshot_amd._lib import lib, check, McmcSets
+    n, cap, min_op = 300, 400, 0.005
+    widths = [3, 3, 45, 1, 3, 4]
+    rng = np.random.default_rng(3)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def setup(logits):
+        par = []
+        for g, w in enumerate(widths):
+            a = np.zeros((cap, w), np.float32); a[:n] = rng.standard_normal((n, w))
+            if g == 3:
+                a[:n, 0] = logits
+            if g == 4:
+                a[:n] = rng.normal(-3, 0.2, (n, 3))
+            par.append(torch.tensor(a.reshape(-1), device=gpu_device))
+        sets = McmcSets()
+        for g in range(6):
+            sets.param[g] = par[g].data_ptr()
+        scratch = torch.empty(int(lib.dvs_mcmc_scratch_bytes(cap)), dtype=torch.uint8, device=gpu_device)
+        check(lib.dvs_mcmc_init_scratch(st, scratch.data_ptr(), cap))
+        return par, sets, scratch
+
+    # no dead splat, and zero growth: nothing changes
+    par, sets, scratch = setup(np.full(n, 1.0, np.float32))
+    before = [p.clone() for p in par]
+    nd = torch.full((1,), 77, dtype=torch.int32).pin_memory()
+    check(lib.dvs_mcmc_relocate(st, n, C.byref(sets), min_op, 1, 0, scratch.data_ptr(), cap, nd.data_ptr()))
+    check(lib.dvs_mcmc_grow(st, n, 0, C.byref(sets), min_op, 2, 0, scratch.data_ptr(), cap))
+    torch.cuda.synchronize()
+    assert int(nd[0]) == 0 and all(torch.equal(a, b) for a, b in zip(par, before))
+    # every splat dead: nothing alive to draw from -> untouched
+    par, sets, scratch = setup(np.full(n, -9.0, np.float32))
+    before = [p.clone() for p in par]
+    check(lib.dvs_mcmc_relocate(st, n, C.byref(sets), min_op, 1, 0, scratch.data_ptr(), cap, nd.data_ptr()))
+    check(lib.dvs_mcmc_grow(st, n, 50, C.byref(sets), min_op, 2, 0, scratch.data_ptr(), cap))
+    torch.cuda.synchronize()
+    assert int(nd[0]) == n and all(torch.equal(a, b) for a, b in zip(par, before))
+    # one live splat: it is the source of all 100 new slots; the relocation ratio saturates at 51
+    logits = np.full(n, -9.0, np.float32); logits[17] = 2.0
+    par, sets, scratch = setup(logits)
+    src_pos = par[0].view(cap, 3)[17].clone()
+    check(lib.dvs_mcmc_grow(st, n, 100, C.byref(sets), min_op, 5, 0, scratch.data_ptr(), cap))
+    torch.cuda.synchronize()
+    assert torch.equal(par[0].view(cap, 3)[n:n + 100], src_pos.expand(100, 3))
+    o = 1 / (1 + np.exp(-2.0)); want, _ = _relocation_np(o, 51, min_op)
+    got = 1 / (1 + np.exp(-par[3].cpu().numpy()[[17, n, n + 99]].astype(np.float64)))
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    # capacity is enforced
+    assert lib.dvs_mcmc_grow(st, n, cap - n + 1, C.byref(sets), min_op, 5, 0, scratch.data_ptr(), cap) != 0
