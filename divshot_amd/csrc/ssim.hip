@@ -110,10 +110,13 @@ k_ssim_fwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
     if (threadIdx.x == 0 && ssim_sum) atomicAdd(ssim_sum + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (DVS_SSIM_SLOTS - 1)), s);
 }
 
-template <bool ACCUM>
+// L1 = true: the kernel also adds the L1 term of the photometric loss, dL = l1_scale * sign(x - y) + scale * dSSIM/dx, and accumulates
+// l1_scale * |x - y| into l1_sum[DVS_SSIM_SLOTS] — one pass over the image instead of two kernels and a read-modify-write of dL.
+template <bool ACCUM, bool L1>
 __global__ void __launch_bounds__(ST * ST)
 k_ssim_bwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, int H, const float* __restrict__ dm_dmu1,
-           const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12, float scale, float* __restrict__ dL) {
+           const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12, float scale, float* __restrict__ dL, float l1_scale,
+           float* __restrict__ l1_sum) {
     __shared__ float sa[SP][SP], sb[SP][SP], sc[SP][SP];
     __shared__ float ha[SP][ST], hb[SP][ST], hc[SP][ST];
     const int ch = blockIdx.z;
@@ -138,10 +141,22 @@ k_ssim_bwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
 #pragma unroll
     for (int k = 0; k < 11; ++k) { const float g = c_gauss[k]; a += g * ha[ly + k][lx]; b += g * hb[ly + k][lx]; c += g * hc[ly + k][lx]; }
     const int gx = x0 + lx, gy = y0 + ly;
+    float l1_local = 0.f;
     if (gx < W && gy < H) {
         const size_t o = plane + (size_t)gy * W + gx;
-        const float g = scale * (a + 2.f * img[o] * b + tgt[o] * c);
+        const float x = img[o], y = tgt[o];
+        float g = scale * (a + 2.f * x * b + y * c);
+        if (L1) {
+            const float d = x - y;
+            g += d > 0.f ? l1_scale : (d < 0.f ? -l1_scale : 0.f);
+            l1_local = fabsf(d) * l1_scale;
+        }
         dL[o] = ACCUM ? dL[o] + g : g;
+    }
+    if (L1) {
+        __shared__ float tmp[4];
+        const float t = block_sum256(l1_local, tmp);
+        if (threadIdx.x == 0 && l1_sum) atomicAdd(l1_sum + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (DVS_SSIM_SLOTS - 1)), t);
     }
 }
 
@@ -161,11 +176,23 @@ int dvs_ssim_backward(void* stream, const float* img, const float* target, int w
     // d(mean SSIM)/dx: the mean is over 3*W*H values
     const float s = scale / (3.0f * (float)width * (float)height);
     if (accumulate)
-        hipLaunchKernelGGL(k_ssim_bwd<true>, grid, dim3(ST * ST), 0, (hipStream_t)stream, img, target, width, height, dm_dmu1,
-                           dm_dsigma1_sq, dm_dsigma12, s, dL_dimg);
+        hipLaunchKernelGGL((k_ssim_bwd<true, false>), grid, dim3(ST * ST), 0, (hipStream_t)stream, img, target, width, height, dm_dmu1,
+                           dm_dsigma1_sq, dm_dsigma12, s, dL_dimg, 0.f, (float*)nullptr);
     else
-        hipLaunchKernelGGL(k_ssim_bwd<false>, grid, dim3(ST * ST), 0, (hipStream_t)stream, img, target, width, height, dm_dmu1,
-                           dm_dsigma1_sq, dm_dsigma12, s, dL_dimg);
+        hipLaunchKernelGGL((k_ssim_bwd<false, false>), grid, dim3(ST * ST), 0, (hipStream_t)stream, img, target, width, height, dm_dmu1,
+                           dm_dsigma1_sq, dm_dsigma12, s, dL_dimg, 0.f, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_loss_l1_ssim_backward(void* stream, const float* img, const float* target, int width, int height, const float* dm_dmu1,
+                              const float* dm_dsigma1_sq, const float* dm_dsigma12, float ssim_weight, float* dL_dimg, float* l1_sum) {
+    if (!img || !target || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg || width <= 0 || height <= 0 ||
+        !(ssim_weight >= 0.f && ssim_weight <= 1.f))
+        return DVS_ERR_INVALID;
+    const dim3 grid((width + ST - 1) / ST, (height + ST - 1) / ST, 3);
+    const float count = 3.0f * (float)width * (float)height;
+    // L = (1-w) mean|x-y| + w (1 - mean SSIM)  ->  dL/dx = (1-w)/count sign(x-y) - w/count dSSIM/dx
+    hipLaunchKernelGGL((k_ssim_bwd<false, true>), grid, dim3(ST * ST), 0, (hipStream_t)stream, img, target, width, height, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, -ssim_weight / count, dL_dimg, (1.0f - ssim_weight) / count, l1_sum);
     return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
 }
 }

@@ -67,7 +67,7 @@ struct GaussianTrainerScene::Impl {
     dvs_fwd_state fwd{};
     std::vector<dvs_camera> cams;
     std::vector<float*> d_targets;
-    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0] = (1-w) L1, d_loss[1..64] = SSIM partial sums
+    float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0..63] = (1-w) L1 partial sums, d_loss[64..127] = SSIM partial sums
     float* d_ssim_maps[3] = {nullptr, nullptr, nullptr};
     float last_loss = 0.f;
     int step = 0;
@@ -189,8 +189,8 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     const size_t img = 3 * (size_t)W * H;
     HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
-    HIP_OR_THROW(hipMalloc((void**)&d_loss, (1 + DVS_SSIM_SLOTS) * sizeof(float)));
-    HIP_OR_THROW(hipMemset(d_loss, 0, (1 + DVS_SSIM_SLOTS) * sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_loss, 2 * DVS_SSIM_SLOTS * sizeof(float)));
+    HIP_OR_THROW(hipMemset(d_loss, 0, 2 * DVS_SSIM_SLOTS * sizeof(float)));
     if (cfg.ssimWeight > 0.f)
         for (int k = 0; k < 3; ++k) HIP_OR_THROW(hipMalloc((void**)&d_ssim_maps[k], img * sizeof(float)));
     dvs_opts opts{sh_max, cfg.mipAntiliased ? 1 : 0, 0, 0, DVS_SHN_TILED};
@@ -348,13 +348,14 @@ void GaussianTrainerScene::trainStep() {
     DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, &m.fwd, nullptr));
     // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25); its gradient goes straight into d_dL
     const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
-    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, (1 + DVS_SSIM_SLOTS) * sizeof(float), m.stream));
-    DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, 1.f - w_ssim, m.d_dL, m.d_loss));
-    if (w_ssim > 0.f) {
+    HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, 2 * DVS_SSIM_SLOTS * sizeof(float), m.stream));
+    if (w_ssim > 0.f) {     // SSIM maps, then the L1 and SSIM gradients in one pass over the image
         DVS_OR_THROW(dvs_ssim_forward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
-                                      m.d_loss + 1));
-        DVS_OR_THROW(dvs_ssim_backward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
-                                       -w_ssim, m.d_dL, 1));
+                                      m.d_loss + DVS_SSIM_SLOTS));
+        DVS_OR_THROW(dvs_loss_l1_ssim_backward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1],
+                                               m.d_ssim_maps[2], w_ssim, m.d_dL, m.d_loss));
+    } else {
+        DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, 1.f, m.d_dL, m.d_loss));
     }
     dvs_splat_grads g{};
     g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
@@ -415,13 +416,13 @@ int GaussianTrainerScene::getCurrentIterations() const { return impl_->step; }
 float GaussianTrainerScene::getCurrentLoss() {
     Impl& m = *impl_;
     if (m.d_loss && m.stream) {
-        float h[1 + DVS_SSIM_SLOTS] = {0.f};
+        float h[2 * DVS_SSIM_SLOTS] = {0.f};
         (void)hipStreamSynchronize(m.stream);
         (void)hipMemcpy(h, m.d_loss, sizeof h, hipMemcpyDeviceToHost);
         const float w = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
-        double ssim_sum = 0;
-        for (int k = 1; k <= DVS_SSIM_SLOTS; ++k) ssim_sum += h[k];
-        m.last_loss = h[0] + (w > 0.f ? w * (1.f - (float)(ssim_sum / (3.0 * m.W * m.H))) : 0.f);
+        double l1 = 0, ssim_sum = 0;
+        for (int k = 0; k < DVS_SSIM_SLOTS; ++k) { l1 += h[k]; ssim_sum += h[DVS_SSIM_SLOTS + k]; }
+        m.last_loss = (float)l1 + (w > 0.f ? w * (1.f - (float)(ssim_sum / (3.0 * m.W * m.H))) : 0.f);
     }
     return m.last_loss;
 }

@@ -31,6 +31,16 @@ class Ssim:
                                    self.maps[1].data_ptr(), self.maps[2].data_ptr(), self.sum.data_ptr()), "dvs_ssim_forward")
         return self.sum.sum().reshape(1) / (3.0 * self.W * self.H)
 
+    def loss_backward(self, img, target, ssim_weight):
+        """After forward(): dL of (1-w) mean|x-y| + w (1 - mean SSIM) in one pass (dvs_loss_l1_ssim_backward).
+        -> (dL [3,H,W], l1 term as a 1-element tensor = (1-w) mean|x-y|)."""
+        dL = torch.empty_like(img)
+        l1 = torch.zeros(64, dtype=torch.float32, device=img.device)
+        check(lib.dvs_loss_l1_ssim_backward(_st(), img.data_ptr(), target.data_ptr(), self.W, self.H, self.maps[0].data_ptr(),
+                                            self.maps[1].data_ptr(), self.maps[2].data_ptr(), float(ssim_weight), dL.data_ptr(), l1.data_ptr()),
+              "dvs_loss_l1_ssim_backward")
+        return dL, l1.sum().reshape(1)
+
     def backward(self, img, target, dL, scale, accumulate=True):
         """dL (+)= scale * d(mean SSIM)/d(img)."""
         check(lib.dvs_ssim_backward(_st(), img.data_ptr(), target.data_ptr(), self.W, self.H, self.maps[0].data_ptr(),

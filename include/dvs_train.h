@@ -35,6 +35,11 @@ int dvs_ssim_forward(void* stream, const float* img, const float* target, int wi
                      float* dm_dsigma1_sq, float* dm_dsigma12, float* ssim_sum);
 int dvs_ssim_backward(void* stream, const float* img, const float* target, int width, int height, const float* dm_dmu1,
                       const float* dm_dsigma1_sq, const float* dm_dsigma12, float scale, float* dL_dimg, int accumulate);
+/* The whole photometric gradient of L = (1-w) mean|x-y| + w (1 - mean SSIM) in one pass after dvs_ssim_forward:
+ *   dL_dimg = (1-w)/(3HW) sign(x-y) - w/(3HW) dSSIM/dx   (overwritten),   l1_sum[0..DVS_SSIM_SLOTS) += (1-w)/(3HW) sum|x-y| (nullable).
+ * Equivalent to dvs_l1_loss_grad_w(weight 1-w) followed by dvs_ssim_backward(scale -w, accumulate). */
+int dvs_loss_l1_ssim_backward(void* stream, const float* img, const float* target, int width, int height, const float* dm_dmu1,
+                              const float* dm_dsigma1_sq, const float* dm_dsigma12, float ssim_weight, float* dL_dimg, float* l1_sum);
 
 /* Fused Adam over one parameter array (count floats): m, v are the moment arrays (same size, DEVICE).
  * step is 1-based. Asynchronous. */

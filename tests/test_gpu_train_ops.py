@@ -65,6 +65,30 @@ def test_ssim_forward_backward(gpu_device):
     np.testing.assert_allclose(g2, 0.25 - 0.2 * g, rtol=1e-5, atol=1e-8)
 
 
+def test_fused_l1_ssim_backward(gpu_device):
+    """dvs_loss_l1_ssim_backward == dvs_l1_loss_grad_w(1-w) followed by dvs_ssim_backward(-w, accumulate), odd image size."""
+    import ctypes as C
+    import torch
+    from divshot_amd._lib import lib, check
+    from divshot_amd.train_ops import Ssim
+    rng = np.random.default_rng(8)
+    H, W, w = 45, 83, 0.2
+    x = torch.tensor(rng.random((3, H, W)).astype(np.float32), device=gpu_device)
+    y = torch.tensor(rng.random((3, H, W)).astype(np.float32), device=gpu_device)
+    y[0, :5] = x[0, :5]                                     # exact ties: sign(0) = 0 in both paths
+    s = Ssim(W, H, gpu_device)
+    s.forward(x, y)
+    dL_f, l1_f = s.loss_backward(x, y, w)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dL_r = torch.empty_like(x); acc = torch.zeros(1, device=gpu_device)
+    check(lib.dvs_l1_loss_grad_w(st, x.data_ptr(), y.data_ptr(), x.numel(), 1.0 - w, dL_r.data_ptr(), acc.data_ptr()))
+    s.backward(x, y, dL_r, -w, accumulate=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dL_f.cpu().numpy(), dL_r.cpu().numpy(), rtol=1e-6, atol=1e-10)
+    want = (1 - w) * float((x - y).abs().double().mean())
+    assert abs(float(l1_f.item()) - want) < 1e-6 * max(want, 1) and abs(float(acc.item()) - want) < 1e-6
+
+
 def test_l1_and_adam(gpu_device):
     import torch
     from divshot_amd.train_ops import l1_loss_grad, adam_step
