@@ -235,6 +235,24 @@ def main():
 
     grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
                                                                                    # (taken before the profiling iterations reuse the buffer)
+    # ---- the composite kernels timed inside the real step: a replica of the timed region with hipEvent pairs around k_render_fwd /
+    # k_render_bwd on the streams they are launched on, never synchronised in between (dvs_enable_kernel_probe). Same concurrency as
+    # the timed region (views pipelined over two streams), so these are the durations rocprofv3 sees for the same command.
+    probe = {}
+    if args.profile_iters > 0:
+        for r_ in rasts:
+            r_.kernel_probe(True)
+        for _ in range(max(1, min(args.steps, 10))):
+            step()
+        torch.cuda.synchronize()
+        acc_p = {"render_fwd": [0.0, 0], "render_bwd": [0.0, 0]}
+        for r_ in rasts:
+            for k_, (ms_, cnt_) in r_.read_kernel_probe().items():
+                acc_p[k_][0] += ms_ * cnt_; acc_p[k_][1] += cnt_
+            r_.kernel_probe(False)
+        probe = {k_: (v_[0] / v_[1] if v_[1] else None) for k_, v_ in acc_p.items()}
+        if dist is not None:
+            dist.barrier()
     # ---- per-stage hipEvent timing (separate iterations; timing mode synchronises per call) --------------
     stage_ms = {}
     if rank == 0 and args.profile_iters > 0:
@@ -266,7 +284,9 @@ def main():
         roofline = None
         if single:
             dom = max(single, key=single.get)
-            achieved = ab[dom] / (single[dom] * 1e-3) / 1e9
+            in_step_ms = probe.get(dom)                       # mean launch duration inside the pipelined step (kernel probe)
+            dur_ms = in_step_ms if in_step_ms else single[dom]
+            achieved = ab[dom] / (dur_ms * 1e-3) / 1e9
             traffic, traffic_src = None, None
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob
@@ -303,7 +323,9 @@ def main():
                 pass
             roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": single[dom], "valu_issue": valu,
+                        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dur_ms,
+                        "avg_launch_ms_isolated": single[dom], "avg_launch_source": ("hipEvent pairs around the kernel inside a replica of the timed "
+                        "region (dvs_enable_kernel_probe)" if in_step_ms else "per-stage hipEvent timing, one view at a time"), "valu_issue": valu,
                         "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r*_pmc_sq.txt), "
                                 "so its HBM fraction is low by construction; see DESIGN.md section 5"}
         stage_table = {}

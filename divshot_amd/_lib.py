@@ -84,6 +84,8 @@ _PROTOS = {
     "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "dvs_keep_bwd_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_enable_kernel_probe": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_read_kernel_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dvs_get_stage_timing": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float))]),
     "dvs_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dvs_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -77,8 +77,14 @@ struct dvs_ctx {
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
-    // stage timing
+    // stage timing: `timing` = every stage, synchronising per call (profiling iterations); `probe` = hipEvent pairs around the
+    // composite kernels only, never synchronising — they are read back once, so the kernels are timed under the concurrency of
+    // the real (pipelined) step
     bool timing = false;
+    bool probe = false;
+    std::vector<hipEvent_t> probe_ev;    // pairs: [2k] before, [2k+1] after
+    std::vector<int> probe_kind;         // per pair: 0 = k_render_fwd, 1 = k_render_bwd
+    size_t probe_used = 0;
     std::vector<hipEvent_t> events;
     std::vector<const char*> ev_names;
     size_t ev_used = 0;
@@ -100,6 +106,12 @@ struct StageTimer {
     void span(const char* name, size_t a, size_t b) { if (c->timing) c->spans.push_back({name, {a, b}}); }
 };
 void timing_reset(dvs_ctx* c) { c->ev_used = 0; c->spans.clear(); }
+hipEvent_t probe_event(dvs_ctx* c, hipStream_t st) {
+    if (c->probe_used == c->probe_ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->probe_ev.push_back(e); }
+    hipEvent_t e = c->probe_ev[c->probe_used++];
+    (void)hipEventRecord(e, st);
+    return e;
+}
 void timing_collect(dvs_ctx* c, bool append) {
     if (!c->timing) return;
     if (!append) { c->out_names.clear(); c->out_ms.clear(); }
@@ -180,6 +192,7 @@ void dvs_destroy(dvs_ctx* c) {
     if (c->total_dev) (void)hipFree(c->total_dev);
     if (c->total_host) (void)hipHostFree(c->total_host);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->probe_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -249,9 +262,11 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles));
     size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     // A7 composite
+    if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
     HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                    c->splat2d.as<float>(), cam->bg, out_rgb,
                                    c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
+    if (c->probe) (void)probe_event(c, st);
     size_t e8 = tm.mark(); tm.span("render_fwd", e7, e8);
 
     dvs_fwd_state& s = c->st;
@@ -276,8 +291,10 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cam, cons
     c->rows_clean = false;
     size_t e1 = tm ? tm->mark() : 0;
     if (tm) tm->span("bwd_zero", e0, e1);
+    if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
     HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
                                    cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
+    if (c->probe) (void)probe_event(c, st);
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
     return DVS_OK;
@@ -407,6 +424,27 @@ int dvs_get_bwd_intermediates(dvs_ctx* c, const float** rows, int* row_floats) {
 }
 
 int dvs_enable_stage_timing(dvs_ctx* c, int enable) { if (!c) return DVS_ERR_INVALID; c->timing = enable != 0; return DVS_OK; }
+int dvs_enable_kernel_probe(dvs_ctx* c, int enable) {
+    if (!c) return DVS_ERR_INVALID;
+    c->probe = enable != 0;
+    c->probe_used = 0; c->probe_kind.clear();
+    return DVS_OK;
+}
+int dvs_read_kernel_probe(dvs_ctx* c, float mean_ms[2], int count[2]) {
+    if (!c || !mean_ms || !count) return DVS_ERR_INVALID;
+    HIPCHECK(hipSetDevice(c->device));
+    double sum[2] = {0, 0};
+    count[0] = count[1] = 0;
+    for (size_t k = 0; k < c->probe_kind.size() && 2 * k + 1 < c->probe_used; ++k) {
+        float ms = 0.f;
+        HIPCHECK(hipEventSynchronize(c->probe_ev[2 * k + 1]));
+        HIPCHECK(hipEventElapsedTime(&ms, c->probe_ev[2 * k], c->probe_ev[2 * k + 1]));
+        sum[c->probe_kind[k]] += ms; count[c->probe_kind[k]]++;
+    }
+    for (int i = 0; i < 2; ++i) mean_ms[i] = count[i] ? (float)(sum[i] / count[i]) : 0.f;
+    c->probe_used = 0; c->probe_kind.clear();
+    return DVS_OK;
+}
 int dvs_get_stage_timing(dvs_ctx* c, const char*** names, const float** ms) {
     if (!c) return 0;
     if (names) *names = c->out_names.data();

@@ -85,6 +85,16 @@ class Rasterizer:
     def enable_timing(self, on=True):
         check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))
 
+    def kernel_probe(self, on=True):
+        """hipEvent pairs around k_render_fwd / k_render_bwd on the caller's stream, no synchronisation (dvs_enable_kernel_probe)."""
+        check(lib.dvs_enable_kernel_probe(self.ctx, 1 if on else 0))
+
+    def read_kernel_probe(self):
+        """-> {"render_fwd": (mean_ms, launches), "render_bwd": (mean_ms, launches)} since the probe was enabled / last read."""
+        ms, cnt = (C.c_float * 2)(), (C.c_int * 2)()
+        check(lib.dvs_read_kernel_probe(self.ctx, ms, cnt), "dvs_read_kernel_probe")
+        return {"render_fwd": (float(ms[0]), int(cnt[0])), "render_bwd": (float(ms[1]), int(cnt[1]))}
+
     def stage_timing(self):
         names = C.POINTER(C.c_char_p)()
         ms = C.POINTER(C.c_float)()

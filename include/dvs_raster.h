@@ -200,6 +200,12 @@ int dvs_keep_bwd_intermediates(dvs_ctx* ctx, int keep);
  * when profiling is enabled. names/ms arrays are ctx-owned; returns the number of stages. */
 int dvs_enable_stage_timing(dvs_ctx* ctx, int enable);
 int dvs_get_stage_timing(dvs_ctx* ctx, const char*** names, const float** ms);
+/* Kernel probe: hipEvent pairs around the two composite kernels (A7, A8) only, recorded on the caller's stream and never
+ * synchronised inside forward/backward, so the kernels are timed under the concurrency of the caller's real (multi-stream) step.
+ * dvs_read_kernel_probe synchronises on the recorded events and returns the mean duration (ms) and launch count of
+ * [0] k_render_fwd, [1] k_render_bwd since the probe was enabled / last read. */
+int dvs_enable_kernel_probe(dvs_ctx* ctx, int enable);
+int dvs_read_kernel_probe(dvs_ctx* ctx, float mean_ms[2], int count[2]);
 
 /* Synchronous copies between host and device on the ctx's device (test plumbing; no torch needed). */
 int dvs_memcpy_d2h(dvs_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
