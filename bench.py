@@ -154,6 +154,9 @@ def main():
     outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
     out = outs[0]
     inv_P = 1.0 / (W * H)
+    # upstream gradient dL/drgb = (rgb - target) / P formed by ONE elementwise kernel per view: rgb * (1/P) + (-target / P), the
+    # second term prepared once (the targets are constant inputs)
+    neg_targets_scaled = [(-t_ * inv_P).contiguous() for t_ in targets]
 
     exchange = args.exchange
     if exchange == "auto":
@@ -182,7 +185,7 @@ def main():
                 if n_ctx > 1 and v < n_ctx:
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
                 img = rasts[c].forward(params, cams[v], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled)
-                dL = (img - targets[v]) * inv_P
+                dL = torch.add(neg_targets_scaled[v], img, alpha=inv_P)
                 g = grads
                 if factorised:
                     g = dict(grads); g["dcolor"] = fx.dcolor_local[v]
