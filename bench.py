@@ -223,9 +223,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # one timing event per step boundary on the main stream (recorded, never waited on inside the loop): steps do not overlap, so
+    # the deltas are the per-step durations; read after the timed region for the p10 / median / p90 spread
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
+        marks[i_].record(main_stream)
         step()
+    marks[args.steps].record(main_stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -281,6 +286,8 @@ def main():
         ab, p = algorithmic_bytes(n, V, T, Ppix, tiles, deg, bool(args.absgrad))
         total_bytes = sum(ab.values())
         ms_per_step = elapsed / args.steps * 1e3
+        step_ms = sorted(marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(args.steps))
+        step_spread = [step_ms[int(q * (len(step_ms) - 1))] for q in (0.1, 0.5, 0.9)] if step_ms else None
         value = world * VPS * args.steps / elapsed
         # dominant kernel = the longest single-kernel stage
         single = {k: stage_ms[k] for k in ("render_bwd", "render_fwd", "preprocess_fwd", "preprocess_bwd", "duplicate") if k in stage_ms}
@@ -344,6 +351,7 @@ def main():
             "metric": "train views/sec (fwd+bwd raster) at 1M splats 1920x1080" if args.workload == "C3" else f"train views/sec (fwd+bwd raster), workload {args.workload}",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "step_ms_p10_p50_p90": step_spread,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {VPS} view(s) per GPU per step"
                                    + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
