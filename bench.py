@@ -286,6 +286,13 @@ def main():
         ab, p = algorithmic_bytes(n, V, T, Ppix, tiles, deg, bool(args.absgrad))
         total_bytes = sum(ab.values())
         ms_per_step = elapsed / args.steps * 1e3
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            device_info = {"name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "compute_units": pr.multi_processor_count,
+                           "clock_mhz": getattr(pr, "clock_rate", 0) / 1e3 if getattr(pr, "clock_rate", 0) else None,
+                           "memory_gb": round(pr.total_memory / 2 ** 30, 1), "host_cores": os.cpu_count()}
+        except Exception:      # noqa: BLE001
+            device_info = None
         step_ms = sorted(marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(args.steps))
         step_spread = [step_ms[int(q * (len(step_ms) - 1))] for q in (0.1, 0.5, 0.9)] if step_ms else None
         value = world * VPS * args.steps / elapsed
@@ -352,6 +359,7 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "step_ms_p10_p50_p90": step_spread,
+            "device": device_info,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {VPS} view(s) per GPU per step"
                                    + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
