@@ -75,8 +75,24 @@ def cpu_baseline(workload, max_seconds=60.0):
         sample = f"{workload} full ({n} splats, {W}x{H}, SH{deg}), 1 view fwd+bwd, OpenMP {cores} threads"
         cpu_baseline.reference = {"img": img, "grads": ref_grads, "fragile": o.get("fragile").astype(bool),
                                   "num_rendered": int(o.get("vals").size)}          # the checker's outputs for view 0 (parity_vs_oracle)
-    return {"value": 1.0 / secs, "unit": "views/s (of the sample)", "cores": cores, "kind": "port",
-            "sample": sample, "seconds": secs, "sample_fraction_of_splats": frac}
+    out = {"value": 1.0 / secs, "unit": "views/s (of the sample)", "cores": cores, "kind": "port",
+           "sample": sample, "seconds": secs, "sample_fraction_of_splats": frac}
+    # the same port on ONE core, on the smaller C2 config (100k splats, 800x800) so that it stays a few seconds (1 thread and all cores)
+    try:
+        from oracle import set_threads
+        n2, W2, H2, deg2, soff2 = WORKLOADS["C2"]
+        spec2 = dv.make_spec(n2, W2, H2, sh_degree=deg2, scale_log_offset=soff2)
+        P2 = dv.synth_splats(spec2); cam2 = dv.synth_camera(spec2, 0); tgt2 = dv.synth_target(spec2, 0)
+        res = {}
+        for label, nthr in (("1_thread", 1), ("all_cores", 0)):
+            set_threads(nthr)
+            t0 = time.perf_counter(); img2 = o.forward(P2, cam2, sh_degree=deg2); o.backward((img2 - tgt2) / tgt2[0].size)
+            res[label] = 1.0 / (time.perf_counter() - t0)
+        set_threads(0)
+        out["c2_views_per_s"] = {"workload": f"C2 ({n2} splats, {W2}x{H2}, SH{deg2}), 1 view fwd+bwd", **res}
+    except Exception as e:      # noqa: BLE001
+        out["c2_views_per_s"] = {"error": repr(e)}
+    return out
 
 
 cpu_baseline.reference = None

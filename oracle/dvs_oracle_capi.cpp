@@ -40,7 +40,11 @@ const void* get_array(dvso::State<T>& S, const std::string& name, uint64_t* coun
 }
 }  // namespace
 
+#include <omp.h>
 extern "C" {
+
+// number of OpenMP threads the oracle uses from now on (0 = all cores); used by the bench's cpu_baseline leg
+void dvso_set_threads(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); }
 
 void* dvso_create(int use_double) {
     Handle* h = new Handle();

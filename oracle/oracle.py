@@ -24,6 +24,7 @@ def _load():
     if _lib is None:
         build()
         _lib = C.CDLL(LIB_PATH)
+        _lib.dvso_set_threads.argtypes = [C.c_int]
         _lib.dvso_create.restype = C.c_void_p
         _lib.dvso_create.argtypes = [C.c_int]
         _lib.dvso_destroy.argtypes = [C.c_void_p]
@@ -50,6 +51,11 @@ _INT_DTYPES = {"radii": np.int32, "rect": np.int32, "flags": np.uint32, "tiles_t
 _SHAPES = {"mean2d": (-1, 2), "conic_opacity": (-1, 4), "rgb": (-1, 3), "rect": (-1, 4), "ranges": (-1, 2),
            "dL_dmean2d": (-1, 2), "dL_dconic_opacity": (-1, 4), "dL_drgb": (-1, 3), "absgrad": (-1, 2),
            "g_pos": (-1, 3), "g_sh0": (-1, 3), "g_shN": (-1, 15, 3), "g_scale": (-1, 3), "g_rot": (-1, 4)}
+
+
+def set_threads(n):
+    """OpenMP threads used by the oracle from now on (0 = all cores)."""
+    _load().dvso_set_threads(int(n))
 
 
 class Oracle:
