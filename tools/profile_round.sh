@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>     e.g. r01e
 # Produces under gpurun_out/: <tag>_bench.json, <tag>_bench_1view_per_step.json, <tag>_bench_under_rocprof.json,
-# <tag>_kernel_stats.txt (rocprofv3 --kernel-trace --stats of the default bench command), <tag>_pmc_sq.txt (SQ counters, own pass).
+# <tag>_kernel_stats.txt (rocprofv3 --kernel-trace --stats of the default bench command), pmc_<tag>_sq.txt (SQ counters, own pass),
+# pmc_<tag>_fetch.txt / pmc_<tag>_write.txt (FETCH_SIZE / WRITE_SIZE, own passes) and <tag>_traffic.json built from them.
 # Copy what should be judged into profiles/ afterwards.
 set -u
 TAG=$1
@@ -15,5 +16,8 @@ rm -rf gpurun_out/prof_${TAG}
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} -o p -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>> $R/gpurun_out/${TAG}_bench.stderr )
 python tools/rocpd_summary.py gpurun_out/prof_${TAG}/p_results.db > gpurun_out/${TAG}_kernel_stats.txt 2>&1
 ( cd /tmp && bash $R/tools/pmc.sh ${TAG}_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY ) > /dev/null 2>&1
+( cd /tmp && bash $R/tools/pmc.sh ${TAG}_fetch FETCH_SIZE ) > /dev/null 2>&1
+( cd /tmp && bash $R/tools/pmc.sh ${TAG}_write WRITE_SIZE ) > /dev/null 2>&1
+python tools/make_traffic_json.py gpurun_out/pmc_${TAG}_fetch.txt gpurun_out/pmc_${TAG}_write.txt > gpurun_out/${TAG}_traffic.json 2>/dev/null
 head -3 gpurun_out/${TAG}_bench.json | cut -c1-300
 head -14 gpurun_out/${TAG}_kernel_stats.txt
