@@ -48,9 +48,22 @@ __device__ __forceinline__ float row_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (8 << 10) | 0x1f));     // xor 8
     return v;
 }
-__device__ __forceinline__ void wave_reduce12(const float v[12], float q[3]) {
+// NV = number of live values (11 with abs-grad, 9 without). The odd value out has no partner to be packed with: instead of a
+// swap against a zero register (v_mov + v_permlane32_swap + v_add = 5 issue slots) it is folded across the two wave halves with
+// ds_bpermute_b32 (lane ^ 32; LDS crossbar) + one v_add; both halves then hold the folded value, which only puts a duplicate into
+// a row no lane publishes. `xaddr` = (lane ^ 32) * 4.
+template <int NV>
+__device__ __forceinline__ void wave_reduce12(const float v[12], float q[3], int xaddr) {
     const float h0 = swap32_add(v[0], v[1]), h1 = swap32_add(v[2], v[3]), h2 = swap32_add(v[4], v[5]);
-    const float h3 = swap32_add(v[6], v[7]), h4 = swap32_add(v[8], v[9]), h5 = swap32_add(v[10], v[11]);
+    const float h3 = swap32_add(v[6], v[7]);
+    float h4, h5;
+    if (NV == 11) {
+        h4 = swap32_add(v[8], v[9]);
+        h5 = v[10] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[10])));
+    } else {                                                   // 9 values: v[8] is the odd one, the sixth register is empty
+        h4 = v[8] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[8])));
+        h5 = 0.f;
+    }
     q[0] = row_sum(swap16_add(h0, h1));
     q[1] = row_sum(swap16_add(h2, h3));
     q[2] = row_sum(swap16_add(h4, h5));
@@ -211,6 +224,7 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
     const int lrow = lane >> 4, lcol = lane & 15;
     const int kv = lcol * 4 + ((lrow == 1) ? 2 : (lrow == 2) ? 1 : lrow);
     const bool publisher = lcol < 3 && kv < (ABSGRAD ? 11 : 9);
+    const int xaddr = (lane ^ 32) << 2;                       // ds_bpermute address of the partner lane in the other wave half
 
     const float T_final = inside ? final_T[pix] : 0.f;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
@@ -293,7 +307,7 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 v[10] = ABSGRAD ? fabsf(__builtin_fmaf(co.z, st, co.y * su)) : 0.f;
                 v[11] = 0.f;
                 float q[3];
-                wave_reduce12(v, q);
+                wave_reduce12<ABSGRAD ? 11 : 9>(v, q, xaddr);
                 if (publisher) {
                     // 11 lanes, 11 consecutive floats of the splat's row: one global_atomic_add_f32 instruction
                     const float val = lcol == 0 ? q[0] : (lcol == 1 ? q[1] : q[2]);
