@@ -31,7 +31,7 @@ class Camera(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("sh_degree", C.c_int32), ("antialias", C.c_int32), ("absgrad", C.c_int32), ("accumulate", C.c_int32),
-                ("shn_layout", C.c_int32), ("_reserved", C.c_int32 * 3)]
+                ("shn_layout", C.c_int32), ("grad_mode", C.c_int32), ("_reserved", C.c_int32 * 2)]
 
 
 class FwdState(C.Structure):
@@ -83,6 +83,7 @@ _PROTOS = {
     "dvs_export_sorted_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "dvs_keep_bwd_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_set_backward_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_enable_kernel_probe": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_read_kernel_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -14,6 +14,7 @@
 //                 dL/dmean2D and dL/dconic), dL/dopacity, dL/drgb x3, |dL/dmean2D| x2, pad
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,6 +78,7 @@ struct dvs_ctx {
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
+    int bwd_variant = DVS_BWD_MM;        // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create)
     // stage timing: `timing` = every stage, synchronising per call (profiling iterations); `probe` = hipEvent pairs around the
     // composite kernels only, never synchronising — they are read back once, so the kernels are timed under the concurrency of
     // the real (pipelined) step
@@ -169,6 +171,7 @@ dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
     if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e, __FILE__, __LINE__); return nullptr; }
     dvs_ctx* c = new dvs_ctx();
     c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h;
+    if (const char* v = getenv("DVS_BWD_VARIANT")) c->bwd_variant = (v[0] == '1' || v[0] == 'r') ? DVS_BWD_REDUCE : DVS_BWD_MM;
     if (hipMalloc((void**)&c->total_dev, 8) != hipSuccess || hipHostMalloc((void**)&c->total_host, 8, hipHostMallocDefault) != hipSuccess) {
         g_last_error = "dvs_create: hipMalloc failed";
         delete c;
@@ -293,7 +296,8 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cam, cons
     if (tm) tm->span("bwd_zero", e0, e1);
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
     HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
-                                   cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad));
+                                   cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
+                                   c->bwd_variant));
     if (c->probe) (void)probe_event(c, st);
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
@@ -308,7 +312,7 @@ static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dv
     HIPCHECK(dvs_launch_preprocess_bwd(st, p->n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
                                        s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
                                        out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor,
-                                       opts->accumulate, c->keep_rows ? 0 : 1, opts->shn_layout));
+                                       opts->accumulate, c->keep_rows ? 0 : 1, opts->shn_layout, opts->grad_mode));
     c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
     c->rows_pending = false;
     if (tm) { size_t e3 = tm->mark(); tm->span("preprocess_bwd", e2, e3); }
@@ -317,6 +321,7 @@ static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dv
 static int check_bwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts, const char* who) {
     static thread_local std::string msg;
     if (!c || !cam || !opts) { msg = std::string(who) + ": null argument"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
+    if (opts->grad_mode != DVS_GRAD_TRUE && opts->grad_mode != DVS_GRAD_LINEAGE) { msg = std::string(who) + ": bad grad_mode"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
     if (!c->have_fwd || (p && c->st.n != p->n) || c->st.width != cam->width || c->st.height != cam->height) {
         msg = std::string(who) + ": no matching forward on this context"; g_last_error = msg.c_str(); return DVS_ERR_STATE;
     }
@@ -411,6 +416,12 @@ int dvs_sh_grad_combine(dvs_ctx* c, void* stream, int n, const float* pos, int s
     }
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(dvs_launch_sh_grad_combine((hipStream_t)stream, n, pos, sh_degree, n_views, campos, dcolor, g_sh0, g_shN, accumulate, shn_layout));
+    return DVS_OK;
+}
+
+int dvs_set_backward_variant(dvs_ctx* c, int variant) {
+    if (!c || (variant != DVS_BWD_MM && variant != DVS_BWD_REDUCE)) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
+    c->bwd_variant = variant;
     return DVS_OK;
 }
 

@@ -15,7 +15,7 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
                                      float* g_pos, float* g_sh0, float* g_shN, float* g_opacity, float* g_scale,
                                      float* g_rot, float* out_absgrad2d /*nullable*/, float* out_mean2d /*nullable*/,
-                                     float* out_dcolor /*nullable*/, int accumulate, int rezero_rows, int shn_tiled);
+                                     float* out_dcolor /*nullable*/, int accumulate, int rezero_rows, int shn_tiled, int grad_mode);
 // g_sh0 / g_shN may be nullptr in dvs_launch_preprocess_bwd (factorised exchange); this rebuilds them from dcolor[n_views,n,3].
 hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
                                       const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled);
@@ -48,4 +48,7 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
                                  uint32_t* n_contrib);
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T, const uint32_t* n_contrib,
-                                 const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad);
+                                 const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad, int grad_mode,
+                                 int variant /*DVS_BWD_*: which A8 kernel*/);
+// A8 kernel variants (dvs_set_backward_variant): same inputs, same 48-B row contract, results equal to fp32 roundoff
+enum { DVS_BWD_MM = 0 /*per-splat sums contracted on the fp32 matrix pipe (default)*/, DVS_BWD_REDUCE = 1 /*cross-lane reduction tree per visit*/ };

@@ -259,7 +259,8 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
                  float4* __restrict__ grad_rows /*[n,3] float4: Sx Sy Sxx Sxy | Syy So r g | b |mx| |my| pad (A8 moments); re-zeroed here*/,
                  float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
                  float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
-                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor, int rezero) {
+                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor, int rezero,
+                 int grad_mode /*dvs_opts.grad_mode: 1 = DVS_GRAD_LINEAGE holds the clamped Jacobian coordinate constant*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
@@ -456,8 +457,10 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         g_tz += -fx * tz2 * gJ00 - fy * tz2 * gJ11;
         g_tz += 2.f * fx * txc * tz3 * gJ02 + 2.f * fy * tyc * tz3 * gJ12;
         const float g_txc = -fx * tz2 * gJ02, g_tyc = -fy * tz2 * gJ12;
-        if (fl & DVS_FLAG_CLAMP_X) g_tz += g_txc * cl_x; else g_tx += g_txc;
-        if (fl & DVS_FLAG_CLAMP_Y) g_tz += g_tyc * cl_y; else g_ty += g_tyc;
+        // clamped branch (txc = cl_x * tz): the true gradient goes through tz; the credited lineage (README.md:95) drops it
+        const float clamp_w = grad_mode == 1 ? 0.f : 1.f;
+        if (fl & DVS_FLAG_CLAMP_X) g_tz += clamp_w * (g_txc * cl_x); else g_tx += g_txc;
+        if (fl & DVS_FLAG_CLAMP_Y) g_tz += clamp_w * (g_tyc * cl_y); else g_ty += g_tyc;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             gp[k] += (cam.view[k * 4 + 0] * g_tx + cam.view[k * 4 + 1] * g_ty) + cam.view[k * 4 + 2] * g_tz;
@@ -712,7 +715,7 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
                                      const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos,
                                      float* g_sh0, float* g_shN, float* g_opacity, float* g_scale, float* g_rot,
                                      float* out_absgrad2d, float* out_mean2d, float* out_dcolor, int accumulate, int rezero,
-                                     int shn_tiled) {
+                                     int shn_tiled, int grad_mode) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     // ROWS: 45 floats per lane of staging; TILED: only the four 3-float groups go through LDS
@@ -720,7 +723,7 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
 #define DVS_PPB(A, T)                                                                                                        \
     hipLaunchKernelGGL((k_preprocess_bwd<A, T>), dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, shN, opacity, scale, rot, cam, deg, \
                        antialias, radii, flags, (float4*)grad_rows, g_pos, g_sh0, g_shN, g_opacity, g_scale, g_rot,           \
-                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero)
+                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero, grad_mode)
     if (accumulate) { if (shn_tiled) DVS_PPB(true, true); else DVS_PPB(true, false); }
     else { if (shn_tiled) DVS_PPB(false, true); else DVS_PPB(false, false); }
 #undef DVS_PPB

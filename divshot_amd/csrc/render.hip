@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(RB)
 k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
              const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
-             float* __restrict__ grow /*[n,12]: Sx Sy Sxx Sxy Syy So r g b |mx| |my| pad (moments, see the loop body)*/) {
+             float* __restrict__ grow /*[n,12]: Sx Sy Sxx Sxy Syy So r g b |mx| |my| pad (moments, see the loop body)*/,
+             int lineage /*dvs_opts.grad_mode == DVS_GRAD_LINEAGE: the gradient passes the 0.99 alpha cap*/) {
     __shared__ BatchLds L;
     __shared__ uint32_t s_max[RB / 64];
     const int tile = tile_of_block(blockIdx.x, num_tiles);
@@ -289,7 +290,8 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
                 const float cd = (c.x * dLp0 + c.y * dLp1) + c.z * dLp2;
                 float dL_dalpha = cd * T - D * inv_1ma;
                 D = D + cd * w;
-                dL_dalpha = (contrib && !(oa > DVS_ALPHA_MAX)) ? dL_dalpha : 0.f;   // the 0.99 clamp blocks the gradient
+                // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE (README.md:95 lineage): it passes as if alpha = opacity * G
+                dL_dalpha = (contrib && (lineage || !(oa > DVS_ALPHA_MAX))) ? dL_dalpha : 0.f;
                 // Per-splat sums are published as MOMENTS of the weight s = dL/dG * G about the splat's mean:
                 //   S_x = sum s dx, S_y = sum s dy, S_xx = sum s dx^2, S_xy = sum s dx dy, S_yy = sum s dy^2, S_o = sum G dL/dalpha
                 // k_preprocess_bwd turns them into dL/dmean2D = -(a S_x + b S_y, c S_y + b S_x) and dL/dconic = (-S_xx/2, -S_xy, -S_yy/2):
@@ -318,6 +320,215 @@ k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
     }
 }
 
+// ---- A8, variant "mm": the per-splat sums as a small dense contraction on the fp32 matrix pipe ---------------------------
+// Same tiling, staging, culling and back-to-front recurrence as k_render_bwd, but the 12-value cross-lane reduction per
+// (wave, splat) visit — 40 % of that kernel's vector instructions — is gone. Every per-splat sum of a visit is linear in just TWO
+// per-pixel scalars, v5 = G dL/dalpha and w = alpha T, against factors that depend on the pixel alone:
+//     sum v5 {1, dx, dy, dx^2, dx dy, dy^2}  (S_o and the five moments; d = mean - pixel is a polynomial in the pixel coordinates)
+//     sum w  {dL/dC_r, dL/dC_g, dL/dC_b}     (colour gradient)
+//     sum |v5| |a dx + b dy| = sum z1 (L1 - a xi - b eta),  z1 = |v5| sgn(l1)   (abs-grad; l1 is linear in the pixel coordinates)
+// so phase A (lane = pixel, the sequential part) only writes (v5, w) of the visit into a wave-private LDS row, and once 16 rows
+// are full phase B contracts the [16 splats x 64 pixels] block against the per-pixel factor matrices with v_mfma_f32_16x16x4_f32
+// (exact fp32, a k-ordered fma chain): A = the (v5 | w | z1 | z2) block read back in MFMA operand layout, B = the monomials
+// {1, xi, eta, xi^2, xi eta, eta^2} of the pixel about the quadrant centre / the pixel's upstream gradient, both constant per
+// wave and held in registers. The epilogue moves the raw moments to the splat's mean (exact algebra, fp32 roundoff of the same
+// size as the direct sums) and publishes the 11 values of the 16 splats with three fully coalesced atomic instructions.
+// The matrix pipe is used as a reduction engine only; nothing here is reshaped into a GEMM that was not one.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MM_SLOTS 16
+#define MM_STRIDE 66      // float2 per slot row: 64 pixels + 2 pad = 528 B, so the 16 rows of a phase-B read hit distinct banks
+
+template <bool ABSGRAD>
+__global__ void __launch_bounds__(RB)
+k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
+                const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
+                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage) {
+    __shared__ BatchLds L;
+    __shared__ uint32_t s_max[RB / 64];
+    __shared__ __attribute__((aligned(16))) float2 s_pair[RB / 64][MM_SLOTS * MM_STRIDE];   // per wave: [slot][pixel] (v5, w); epilogue scratch
+    const int tile = tile_of_block(blockIdx.x, num_tiles);
+    if (tile >= num_tiles) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qx0 = tx * DVS_TILE + (wave & 1) * 8, qy0 = ty * DVS_TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
+    float2* const pairp = s_pair[wave];
+    float* const sc = reinterpret_cast<float*>(pairp);       // epilogue scratch: [16][4][16] floats, then [16][12] at float 1024
+    const int sl = lane & 15, kq = lane >> 4;                // MFMA operand coordinates of this lane: row/column sl, k index kq
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f;
+    if (inside) { dLp0 = dL_dout[pix]; dLp1 = dL_dout[P + pix]; dLp2 = dL_dout[2 * P + pix]; }
+    const float bg_dot = (bg0 * dLp0 + bg1 * dLp1) + bg2 * dLp2;
+
+    uint32_t wmax = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+    if (lane == 0) s_max[wave] = wmax;
+    // B operands (constant per wave). Step s of phase B covers the four pixels 4s .. 4s+3 of the quadrant (row s >> 1,
+    // columns 4 (s & 1) ..): lane (sl, kq) holds column sl of pixel 4s + kq.
+    //   ball[s]: monomials of (xi, eta) = pixel - quadrant centre in columns 0..5;  bgr[s]: the pixel's dL/dC in columns 0..2
+    reinterpret_cast<float4*>(sc)[lane] = make_float4(dLp0, dLp1, dLp2, 0.f);
+    __syncthreads();
+    float ball[16], bgr[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float xi = (float)(4 * (s & 1) + kq) - 3.5f, eta = (float)(s >> 1) - 3.5f;
+        ball[s] = sl == 0 ? 1.f : sl == 1 ? xi : sl == 2 ? eta : sl == 3 ? xi * xi : sl == 4 ? xi * eta : sl == 5 ? eta * eta : 0.f;
+        bgr[s] = sc[(4 * s + kq) * 4 + min(sl, 3)];
+    }
+    const int wave_last = (int)__builtin_amdgcn_readfirstlane(wmax);
+    uint32_t todo = 0;
+#pragma unroll
+    for (int w = 0; w < RB / 64; ++w) todo = max(todo, s_max[w]);
+    if (todo == 0) return;
+    const float cx = (float)qx0 + 3.5f, cy = (float)qy0 + 3.5f;
+
+    // phase B + epilogue for the `count` filled rows; jv: lane s (< 16) holds the batch index of row s
+    auto flush = [&](int count, uint32_t jv) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float P1a = 0.f, P1b = 0.f, P2a = 0.f, P2b = 0.f, nb = 0.f, nc = 0.f;
+        if (ABSGRAD) {
+            const int js = __shfl((int)jv, sl, 64);
+            const float4 xy = L.xyc[js];
+            const float4 cg = L.cog[js];
+            const float mu = xy.x - cx, nu = xy.y - cy, xi0 = (float)kq - 3.5f;
+            const float L1 = cg.x * mu + cg.y * nu, L2 = cg.y * mu + cg.z * nu;
+            P1a = L1 - cg.x * xi0; P1b = P1a - 4.f * cg.x; P2a = L2 - cg.y * xi0; P2b = P2a - 4.f * cg.y;
+            nb = -cg.y; nc = -cg.z;
+        }
+        f32x4 accv = {0.f, 0.f, 0.f, 0.f}, accw = accv, acc1 = accv, acc2 = accv;
+        const float2* rp = pairp + sl * MM_STRIDE + kq;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float2 vw = rp[4 * s];
+            accv = __builtin_amdgcn_mfma_f32_16x16x4f32(vw.x, ball[s], accv, 0, 0, 0);
+            accw = __builtin_amdgcn_mfma_f32_16x16x4f32(vw.y, bgr[s], accw, 0, 0, 0);
+            if (ABSGRAD) {
+                const float eta = (float)(s >> 1) - 3.5f;
+                const float l1 = __builtin_fmaf(nb, eta, (s & 1) ? P1b : P1a), l2 = __builtin_fmaf(nc, eta, (s & 1) ? P2b : P2a);
+                const float z1 = __builtin_copysignf(vw.x, l1), z2 = __builtin_copysignf(vw.x, l2);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(z1, ball[s], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(z2, ball[s], acc2, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // D[row = 4 kq + r][column sl] -> scratch [row][type][column]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* o = sc + (4 * kq + r) * 64 + sl;
+            o[0] = accv[r]; o[16] = accw[r];
+            if (ABSGRAD) { o[32] = acc1[r]; o[48] = acc2[r]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* sc2 = sc + 1024;
+        if (lane < count) {                       // lane = row: raw moments about the quadrant centre -> moments about the mean
+            const int j = (int)jv;
+            const float4 m0 = *reinterpret_cast<const float4*>(sc + lane * 64);          // R_1 R_xi R_eta R_xixi
+            const float2 m1 = *reinterpret_cast<const float2*>(sc + lane * 64 + 4);      // R_xieta R_etaeta
+            const float4 cw = *reinterpret_cast<const float4*>(sc + lane * 64 + 16);     // colour sums
+            const float4 xy = L.xyc[j];
+            const float4 cg = L.cog[j];
+            const float4 zo = L.zoir[j];
+            const float mu = xy.x - cx, nu = xy.y - cy, op = zo.y;
+            const float sx = mu * m0.x - m0.y, sy = nu * m0.x - m0.z;              // sum v5 dx, sum v5 dy
+            const float sxx = __builtin_fmaf(mu, sx, m0.w - mu * m0.y);              // mu^2 R1 - 2 mu Rxi + Rxixi
+            const float sxy = __builtin_fmaf(mu, sy, m1.x - nu * m0.y);              // mu nu R1 - mu Reta - nu Rxi + Rxieta
+            const float syy = __builtin_fmaf(nu, sy, m1.y - nu * m0.z);              // nu^2 R1 - 2 nu Reta + Retaeta
+            float ax = 0.f, ay = 0.f;
+            if (ABSGRAD) {
+                const float4 z1 = *reinterpret_cast<const float4*>(sc + lane * 64 + 32);
+                const float4 z2 = *reinterpret_cast<const float4*>(sc + lane * 64 + 48);
+                const float L1 = cg.x * mu + cg.y * nu, L2 = cg.y * mu + cg.z * nu;
+                ax = op * ((L1 * z1.x - cg.x * z1.y) - cg.y * z1.z);
+                ay = op * ((L2 * z2.x - cg.y * z2.y) - cg.z * z2.z);
+            }
+            float4* dst = reinterpret_cast<float4*>(sc2 + lane * 12);
+            dst[0] = make_float4(op * sx, op * sy, op * sxx, op * sxy);
+            dst[1] = make_float4(op * syy, m0.x, cw.x, cw.y);
+            dst[2] = make_float4(cw.z, ax, ay, zo.z /* splat id bits */);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 16 rows x 12 floats = 3 x 64 lanes: consecutive lanes add consecutive floats of a splat's 48-B row
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = 64 * i + lane;
+            const int row = (e * 43691) >> 19;            // e / 12 for e < 192
+            const int comp = e - row * 12;
+            if (row < count && comp < (ABSGRAD ? 11 : 9)) {
+                const uint32_t id = __float_as_uint(sc2[row * 12 + 11]);
+                atomicAdd(&grow[(size_t)id * 12 + comp], sc2[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    float T = T_final;
+    float D = T_final * bg_dot;
+    int slot = 0;                 // rows filled so far (wave-uniform)
+    uint32_t jvec = 0;
+    const int nbatch = (int)((todo + RB - 1) / RB);
+    for (int b = nbatch - 1; b >= 0; --b) {
+        const int base = b * RB;
+        const int cnt = min(RB, (int)todo - base);
+        __syncthreads();
+        stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
+        __syncthreads();
+#pragma unroll 1
+        for (int lw = RB / 64 - 1; lw >= 0; --lw) {
+            const int lim = wave_last - base - lw * 64;
+            if (lim <= 0) continue;
+            uint64_t m = uniform_u64(L.qmask[lw][wave]);
+            if (lim < 64) m &= (1ull << lim) - 1ull;
+            while (m) {
+                const int bit = 63 - __builtin_clzll(m);
+                m &= ~(1ull << bit);
+                const int j = lw * 64 + bit;
+                const uint32_t k = (uint32_t)(base + j);
+                const float4 xy = L.xyc[j];
+                const float2 zo2 = *reinterpret_cast<const float2*>(&L.zoir[j]);
+                const float dx = xy.x - pxf, dy = xy.y - pyf;
+                const float p2 = __builtin_fmaf(zo2.x * dy, dy, __builtin_fmaf(xy.w, dy, xy.z * dx) * dx);   // same expression as the forward
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float oa = zo2.y * G;
+                const float alpha = fminf(DVS_ALPHA_MAX, oa);
+                const bool contrib = (k < last) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
+                if (!__any(contrib)) continue;
+                const float3 c = make_float3(L.zoir[j].w, L.cog[j].w, L.bl[j].x);
+                const float al = contrib ? alpha : 0.f;
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);
+                T = T * inv_1ma;
+                const float w = al * T;
+                const float cd = (c.x * dLp0 + c.y * dLp1) + c.z * dLp2;
+                const float dL_dalpha = cd * T - D * inv_1ma;
+                D = D + cd * w;
+                // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE: it passes as if alpha = opacity * G
+                const bool gate = contrib && (lineage || !(oa > DVS_ALPHA_MAX));
+                const float v5 = gate ? G * dL_dalpha : 0.f;
+                pairp[slot * MM_STRIDE + lane] = make_float2(v5, w);
+                // lane `slot` of jvec = j (both wave-uniform; one SGPR per VALU instruction on gfx9, so the lane select goes through m0)
+                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(jvec) : "s"(j), "s"(slot) : "m0");
+                if (++slot == MM_SLOTS) { flush(MM_SLOTS, jvec); slot = 0; }
+            }
+        }
+        if (slot > 0) { flush(slot, jvec); slot = 0; }        // the rows refer to L by batch index: publish before L is restaged
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color, float* final_T,
@@ -333,17 +544,16 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
 
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T, const uint32_t* n_contrib,
-                                 const float* dL_dout, float* grad_rows, int absgrad) {
+                                 const float* dL_dout, float* grad_rows, int absgrad, int grad_mode, int variant) {
     const int num_tiles = tiles_x * tiles_y;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
-    if (absgrad)
-        hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges,
-                           sorted_splat, (const float4*)splat2d, bg[0], bg[1], bg[2], final_T,
-                           n_contrib, dL_dout, grad_rows);
-    else
-        hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges,
-                           sorted_splat, (const float4*)splat2d, bg[0], bg[1], bg[2], final_T,
-                           n_contrib, dL_dout, grad_rows);
+    const int lineage = grad_mode == 1 ? 1 : 0;
+#define DVS_RB(KERNEL)                                                                                                          \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,        \
+                       (const float4*)splat2d, bg[0], bg[1], bg[2], final_T, n_contrib, dL_dout, grad_rows, lineage)
+    if (variant == DVS_BWD_REDUCE) { if (absgrad) DVS_RB(k_render_bwd<true>); else DVS_RB(k_render_bwd<false>); }
+    else { if (absgrad) DVS_RB(k_render_bwd_mm<true>); else DVS_RB(k_render_bwd_mm<false>); }
+#undef DVS_RB
     return hipGetLastError();
 }

@@ -82,6 +82,11 @@ class Rasterizer:
     def keep_intermediates(self, on=True):
         check(lib.dvs_keep_bwd_intermediates(self.ctx, 1 if on else 0))
 
+    def set_backward_variant(self, variant):
+        """A8 kernel: 0 / "mm" = sums contracted on the fp32 matrix pipe (default), 1 / "reduce" = cross-lane reduction per visit."""
+        v = {"mm": 0, "reduce": 1}.get(variant, variant)
+        check(lib.dvs_set_backward_variant(self.ctx, int(v)), "dvs_set_backward_variant")
+
     def enable_timing(self, on=True):
         check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))
 
@@ -102,11 +107,12 @@ class Rasterizer:
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
     # -- the two ops -------------------------------------------------------------------------
-    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False):
+    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False, grad_mode=0):
         """params: dict of CUDA float32 tensors (A0 layout; params["shN"] in the tiled layout when shn_tiled).
+        grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (dvs_raster.h) — used by the backward calls that follow.
         Returns out_rgb [3,H,W] (CUDA)."""
         sp = self._splats(params, shn_tiled)
-        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled))
+        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled), int(grad_mode))
         self._tiled = bool(shn_tiled)
         if out is None:
             out = torch.empty((3, cam.height, cam.width), dtype=torch.float32, device=self.tdev)
@@ -126,7 +132,7 @@ class Rasterizer:
             # the tiled shN array has pad lanes (splats >= n of the last tile) that the kernels never write: keep them defined
             grads = {k: (torch.zeros_like(params[k]) if (k == "shN" and self._tiled) else torch.empty_like(params[k])) for k in PARAM_KEYS}
             accumulate = False
-        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout)
+        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout, self._opts.grad_mode)
         if self._opts.absgrad and "absgrad2d" not in grads:
             grads["absgrad2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
         if want_mean2d and "mean2d" not in grads:

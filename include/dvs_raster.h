@@ -94,8 +94,19 @@ typedef struct dvs_opts {
     int32_t absgrad;       /* also accumulate |dL/dmean2D| (main.cpp:44 --absgrad) */
     int32_t accumulate;    /* backward: 0 = overwrite gradient rows, 1 = add into them (multi-view batches) */
     int32_t shn_layout;    /* DVS_SHN_ROWS (default 0) or DVS_SHN_TILED */
-    int32_t _reserved[3];
+    int32_t grad_mode;     /* DVS_GRAD_TRUE (default 0) or DVS_GRAD_LINEAGE: which backward the two non-smooth points of the forward get */
+    int32_t _reserved[2];
 } dvs_opts;
+
+/* dvs_opts.grad_mode. The forward is identical in both modes; they differ only where the forward is not smooth:
+ *   DVS_GRAD_TRUE    the exact derivative of the forward: a pixel whose alpha hit the 0.99 cap passes no gradient to the
+ *                    conic / mean / opacity of that splat (d min(0.99, x)/dx = 0 there), and on the clamped branch of the EWA
+ *                    Jacobian (|t.x/t.z| > 1.3 tan_fov) the clamped coordinate t.x = +-lim * t.z is differentiated through t.z.
+ *                    This is the mode the fp64 finite-difference checks validate.
+ *   DVS_GRAD_LINEAGE the backward of the rasterizer lineage the reference credits (README.md:95): the gradient flows through
+ *                    the alpha cap as if alpha were opacity*G, and on the clamped Jacobian branch the clamped coordinate is held
+ *                    constant (its gradient to t.x is dropped, none is added to t.z). libgstrain.so uses this mode. */
+enum { DVS_GRAD_TRUE = 0, DVS_GRAD_LINEAGE = 1 };
 
 /* Saved forward state. DEVICE pointers into ctx-owned arenas; valid until the next
  * dvs_raster_forward on the same ctx. Exposed so the parity tests can diff every stage. */
@@ -177,6 +188,12 @@ int dvs_sh_grad_combine(dvs_ctx* ctx, void* stream, int n, const float* pos, int
                         const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_layout);
 /* Convert an shN array (DEVICE, src != dst) between DVS_SHN_ROWS [n*45] and DVS_SHN_TILED [ceil(n/64)*64*48]. */
 int dvs_shn_relayout(dvs_ctx* ctx, void* stream, int n, const float* src, float* dst, int to_tiled);
+
+/* The composite backward (A8) exists in two kernels with the same inputs and the same output rows (equal to fp32 roundoff):
+ *   0 "mm"     (default) per-pixel recurrence, per-splat sums contracted on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
+ *   1 "reduce" per-pixel recurrence, a 12-value cross-lane reduction tree per (wave, splat) visit (the round-1 kernel)
+ * The environment variable DVS_BWD_VARIANT (0/1) sets the default of new contexts. */
+int dvs_set_backward_variant(dvs_ctx* ctx, int variant);
 
 /* Stage-level entry points (used by the parity tests and the profiler harness). */
 /* radix sort of (u32 key, u32 value) pairs over key bits [bit_lo, bit_hi), stable, LSD, 8-bit digits.

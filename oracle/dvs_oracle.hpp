@@ -386,9 +386,10 @@ template <class T> void render_forward(State<T>& S) {
 }
 
 // ---- A8: alpha-composite backward ----------------------------------------------------------------
-// True gradient of the forward above (the 0.99 clamp blocks the gradient to conic/mean/opacity, as
-// autograd of min() does; verified against fp64 finite differences).  Per-instance partials are
-// written at their sorted position and summed per splat in sorted order, so the result is
+// opts.grad_mode = DVS_GRAD_TRUE: true gradient of the forward above (the 0.99 clamp blocks the gradient to
+// conic/mean/opacity, as autograd of min() does; verified against fp64 finite differences).
+// opts.grad_mode = DVS_GRAD_LINEAGE: the backward of the lineage the reference credits (README.md:95), see dvs_raster.h.
+// Per-instance partials are written at their sorted position and summed per splat in sorted order, so the result is
 // deterministic regardless of thread count.
 template <class T> void render_backward(State<T>& S, const T* dL_dout /*[3,H,W]*/) {
     const int W = S.W, H = S.H, n = S.n;
@@ -437,7 +438,9 @@ template <class T> void render_backward(State<T>& S, const T* dL_dout /*[3,H,W]*
                     dL_dalpha = dL_dalpha * Tr;
                     last_alpha = alpha;
                     dL_dalpha = dL_dalpha + (-T_final / (T(1) - alpha)) * bg_dot;
-                    if (oa > T(kAlphaMax)) continue;          // clamped: alpha is constant w.r.t. G and opacity
+                    // clamped: alpha is constant w.r.t. G and opacity (DVS_GRAD_TRUE). The credited lineage (README.md:95)
+                    // lets the gradient through the cap as if alpha = opacity*G (DVS_GRAD_LINEAGE).
+                    if (oa > T(kAlphaMax) && S.opts.grad_mode == DVS_GRAD_TRUE) continue;
                     const T dL_dG = co[3] * dL_dalpha;
                     const T gdx = G * dx, gdy = G * dy;
                     const T dG_ddelx = -gdx * co[0] - gdy * co[1];
@@ -601,8 +604,11 @@ template <class T> void preprocess_backward(State<T>& S) {
         g_tz += -fx * tz2 * gJ00 - fy * tz2 * gJ11;
         g_tz += T(2) * fx * txc * tz3 * gJ02 + T(2) * fy * tyc * tz3 * gJ12;     // at fixed txc, tyc
         const T g_txc = -fx * tz2 * gJ02, g_tyc = -fy * tz2 * gJ12;
-        if (fl & 8u) g_tz += g_txc * cl_x; else g_tx += g_txc;                      // txc = cl_x * tz when clamped
-        if (fl & 16u) g_tz += g_tyc * cl_y; else g_ty += g_tyc;
+        // clamped branch: txc = cl_x * tz. DVS_GRAD_TRUE differentiates it through tz; DVS_GRAD_LINEAGE holds the clamped
+        // coordinate constant (the credited lineage multiplies dL/dt.x by 0 there and adds nothing to dL/dt.z).
+        const bool lineage = S.opts.grad_mode == DVS_GRAD_LINEAGE;
+        if (fl & 8u) { if (!lineage) g_tz += g_txc * cl_x; } else g_tx += g_txc;
+        if (fl & 16u) { if (!lineage) g_tz += g_tyc * cl_y; } else g_ty += g_tyc;
         for (int k = 0; k < 3; ++k)
             gp[k] += (T(cam.view[k * 4 + 0]) * g_tx + T(cam.view[k * 4 + 1]) * g_ty) + T(cam.view[k * 4 + 2]) * g_tz;
 

@@ -75,6 +75,12 @@ int dvso_backward(void* hp, const void* dL_dout) {
     return 0;
 }
 
+// which backward the two non-smooth points of the forward get from now on (dvs_opts.grad_mode: DVS_GRAD_TRUE / DVS_GRAD_LINEAGE)
+void dvso_set_grad_mode(void* hp, int mode) {
+    Handle* h = (Handle*)hp;
+    h->f.opts.grad_mode = mode; h->d.opts.grad_mode = mode;
+}
+
 const void* dvso_array(void* hp, const char* name, uint64_t* count, int* elem_bytes) {
     Handle* h = (Handle*)hp;
     return h->is_double ? get_array(h->d, name, count, elem_bytes) : get_array(h->f, name, count, elem_bytes);

@@ -32,6 +32,7 @@ def _load():
         _lib.dvso_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p, C.c_void_p]
         _lib.dvso_backward.restype = C.c_int
         _lib.dvso_backward.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.dvso_set_grad_mode.argtypes = [C.c_void_p, C.c_int]
         _lib.dvso_array.restype = C.c_void_p
         _lib.dvso_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib.dvso_interactions.restype = C.c_uint64
@@ -73,17 +74,21 @@ class Oracle:
             self.lib.dvso_destroy(self.h)
             self.h = None
 
-    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False):
+    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, grad_mode=0):
         """params: dict of numpy arrays (A0 layout); cam: divshot_amd.Camera (ctypes struct, same layout as dvs_camera)."""
         arrs = [np.ascontiguousarray(params[k], dtype=self.dtype) for k in ("pos", "sh0", "shN", "opacity", "scale", "rot")]
         n = arrs[0].shape[0]
-        opts = (C.c_int32 * 8)(sh_degree, int(antialias), int(absgrad), 0, 0, 0, 0, 0)
+        opts = (C.c_int32 * 8)(sh_degree, int(antialias), int(absgrad), 0, 0, int(grad_mode), 0, 0)     # dvs_opts
+        # (grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE — only the backward differs)
         self.W, self.H = cam.width, cam.height
         rc = self.lib.dvso_forward(self.h, n, *[a.ctypes.data for a in arrs], C.addressof(cam), C.addressof(opts))
         assert rc == 0
         return self.get("out_color").reshape(3, self.H, self.W)
 
-    def backward(self, dL_dout):
+    def backward(self, dL_dout, grad_mode=None):
+        """grad_mode: None = the mode given to forward(); 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (the forward does not depend on it)."""
+        if grad_mode is not None:
+            self.lib.dvso_set_grad_mode(self.h, int(grad_mode))
         g = np.ascontiguousarray(dL_dout, dtype=self.dtype)
         assert g.shape == (3, self.H, self.W)
         rc = self.lib.dvso_backward(self.h, g.ctypes.data)

@@ -41,8 +41,10 @@ def sh_color(deg, sh0, shN, dirs):
     return torch.clamp_min(col + 0.5, 0.0)
 
 
-def render(params, cam, sh_degree=3, antialias=False, dtype=torch.float64):
-    """params: dict of numpy arrays (A0 layout); cam: ctypes dvs_camera. Returns (image [3,H,W], leaf tensors)."""
+def render(params, cam, sh_degree=3, antialias=False, dtype=torch.float64, grad_mode=0):
+    """params: dict of numpy arrays (A0 layout); cam: ctypes dvs_camera. Returns (image [3,H,W], leaf tensors).
+    grad_mode 0 = autograd of the forward as written (DVS_GRAD_TRUE); 1 = DVS_GRAD_LINEAGE (include/dvs_raster.h): the same forward
+    values, but the 0.99 alpha cap is a straight-through min and a clamped EWA-Jacobian coordinate is a constant."""
     P = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in params.items()}
     W, H = cam.width, cam.height
     view = torch.tensor(list(cam.view), dtype=dtype).reshape(4, 4)      # view[c, r]
@@ -69,6 +71,9 @@ def render(params, cam, sh_degree=3, antialias=False, dtype=torch.float64):
     limx, limy = float(np.float32(1.3)) * cam.tan_fovx, float(np.float32(1.3)) * cam.tan_fovy
     txc = torch.clamp(t[:, 0] / tz, -limx, limx) * tz
     tyc = torch.clamp(t[:, 1] / tz, -limy, limy) * tz
+    if grad_mode == 1:      # the lineage multiplies dL/dt.x by 0 on the clamped branch and differentiates t.z at fixed clamped coordinate
+        txc = torch.where((t[:, 0] / tz).abs() > limx, txc.detach(), t[:, 0])
+        tyc = torch.where((t[:, 1] / tz).abs() > limy, tyc.detach(), t[:, 1])
     zero = torch.zeros_like(tz)
     J = torch.stack([cam.focal_x / tz, zero, -cam.focal_x * txc / (tz * tz),
                      zero, cam.focal_y / tz, -cam.focal_y * tyc / (tz * tz)], 1).reshape(-1, 2, 3)
@@ -107,7 +112,10 @@ def render(params, cam, sh_degree=3, antialias=False, dtype=torch.float64):
     with torch.no_grad():
         tile_px, tile_py = torch.floor(px / 16), torch.floor(py / 16)
         in_rect = (tile_px >= rminx[o]) & (tile_px < rmaxx[o]) & (tile_py >= rminy[o]) & (tile_py < rmaxy[o])
-    alpha = torch.clamp_max(opac[o] * torch.exp(power), float(np.float32(0.99)))
+    raw = opac[o] * torch.exp(power)
+    alpha = torch.clamp_max(raw, float(np.float32(0.99)))
+    if grad_mode == 1:      # the lineage's backward uses dL/dG = opacity * dL/dalpha whether or not the cap was hit
+        alpha = raw + (alpha - raw).detach()
     keep = in_rect & (power <= 0) & (alpha >= 1.0 / 255.0)
     alpha = torch.where(keep, alpha, torch.zeros_like(alpha))
     T_incl = torch.cumprod(1.0 - alpha, dim=1)

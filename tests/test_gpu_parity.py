@@ -7,6 +7,8 @@ against the fp64 oracle: every element within 1e-4 rel + 1e-5 of the group's max
 for sums that cancel: a per-splat gradient is a sum of hundreds of signed per-pixel terms accumulated in
 fp32), and the whole group within 1e-5 relative L2 error.
 """
+import json
+import os
 import numpy as np
 import pytest
 import divshot_amd as dv
@@ -53,6 +55,7 @@ def rast(gpu_device):
 
 
 def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
+    """forward once; backward for every (grad_mode, A8 kernel variant) combination on the same upstream gradient"""
     import torch
     from divshot_amd.raster import params_to_device
     Pd = params_to_device(P, rast.tdev)
@@ -62,17 +65,27 @@ def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
     saved = rast.saved()
     keys = rast.sorted_keys()
     dL = torch.from_numpy((img_h - tgt) / tgt[0].size).to(rast.tdev)
-    grads = rast.backward(dL, want_mean2d=True)
-    torch.cuda.synchronize()
-    inter = rast.bwd_intermediates()
-    return img_h, saved, keys, {k: v.cpu().numpy() for k, v in grads.items()}, inter, (img_h - tgt) / tgt[0].size
+    runs = {}
+    for mode in (0, 1):
+        for variant in ("mm", "reduce"):
+            rast.set_backward_variant(variant)
+            rast._opts.grad_mode = mode
+            grads = rast.backward(dL, want_mean2d=True)
+            torch.cuda.synchronize()
+            runs[(mode, variant)] = ({k: v.cpu().numpy() for k, v in grads.items()}, rast.bwd_intermediates())
+    rast.set_backward_variant("mm")
+    rast._opts.grad_mode = 0
+    return img_h, saved, keys, runs, (img_h - tgt) / tgt[0].size
+
+
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_pipeline_parity(rast, oracle_mod, name):
     n, W, H, deg, seed, soff, aa, bg = CONFIGS[name]
     spec, P, cam, tgt = scene(n, W, H, deg, seed, scale_offset=soff, bg=bg)
-    img, saved, keys, grads, inter, dL = _run_gpu(rast, P, cam, tgt, deg, aa)
+    img, saved, keys, runs, dL = _run_gpu(rast, P, cam, tgt, deg, aa)
 
     o = oracle_mod.Oracle(np.float32)
     ref_img = o.forward(P, cam, sh_degree=deg, antialias=aa)
@@ -114,48 +127,81 @@ def test_pipeline_parity(rast, oracle_mod, name):
     frag_any = frag | o64.get("fragile").astype(bool)
     tainted = np.zeros(n, bool)
     fy, fx = np.where(frag_any)
-    m2, rad = saved["mean2d"], saved["radii"]
+    m2, rad, co = saved["mean2d"].astype(np.float64), saved["radii"], saved["conic_opacity"].astype(np.float64)
     for x, y in zip(fx, fy):
-        tainted |= (np.abs(m2[:, 0] - x) <= rad) & (np.abs(m2[:, 1] - y) <= rad) & (rad > 0)
+        # a flipped decision at (x, y) moves the gradient of every splat that can contribute there (alpha >= 1/255 up to the
+        # fragility margin) — not of splats whose 3-sigma box merely covers the pixel
+        ddx, ddy = m2[:, 0] - x, m2[:, 1] - y
+        power = -0.5 * (co[:, 0] * ddx * ddx + co[:, 2] * ddy * ddy) - co[:, 1] * ddx * ddy
+        alpha = np.minimum(0.99, co[:, 3] * np.exp(np.minimum(power, 0.0)))
+        tainted |= (np.abs(ddx) <= rad) & (np.abs(ddy) <= rad) & (rad > 0) & (power <= 1e-6) & (alpha >= (1.0 / 255.0) * (1 - 1e-3))
+    # the tainted set is the carve-out of this test: bounded for every config and written to the report
     if not name.startswith(("dense", "rnd")):      # huge splats: one fragile pixel taints everything that covers it
         assert tainted.mean() < 0.10, tainted.mean()
-    ref64 = o64.backward(dL)
-    ref32 = o.backward(dL)
-    if not np.array_equal(o64.get("n_contrib")[~frag_any], nc_ref[~frag_any]) or not np.array_equal(o64.get("vals"), o.get("vals")):
-        # fp64 binned differently somewhere (a radius at an integer boundary): the fp32 oracle is the strict reference
-        o64, ref64 = o, ref32
+    else:
+        assert tainted.mean() < 0.65, tainted.mean()
+    clean = ~tainted
+    report = {"config": name, "n": n, "visible": int((saved["radii"] > 0).sum()), "T": int(rast.num_rendered),
+              "fragile_pixel_fraction": float(frag_any.mean()), "tainted_splat_fraction": float(tainted.mean()), "runs": {}}
 
     # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
     # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-2 relative L2
     # of the fp32 oracle (one flipped 1/255-alpha contribution moves a gradient by ~1e-3 of its magnitude).
-    clean = ~tainted
-
-    def check_group(name, got, want64, want32):
+    def check_group(tag, rec, got, want64, want32):
         got = np.asarray(got, np.float64); want64 = np.asarray(want64, np.float64); want32 = np.asarray(want32, np.float64)
         scale = np.abs(want64).max()
+        out = {}
         if clean.any():
             g, w = got[clean], want64[clean]
             err = np.abs(g - w)
             tol = 1e-4 * np.abs(w) + 1e-5 * scale
-            assert (err <= tol).all(), f"{name}: worst {(err / tol).max()}, frac ok {(err <= tol).mean()}"
             l2 = np.linalg.norm((g - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-300)
+            out["clean_worst_err_over_tol"] = float((err / np.maximum(tol, 1e-300)).max()); out["clean_rel_l2"] = float(l2)
+            rec[tag] = out
+            assert (err <= tol).all(), f"{tag}: worst {(err / tol).max()}, frac ok {(err <= tol).mean()}"
             # scenes of a few dozen splats have no averaging over rows: their L2 bound is the plain fp32 one (still 2x inside 1e-4)
-            assert l2 < (1e-5 if n >= 1000 else 5e-5), f"{name}: relative L2 error {l2}"
+            assert l2 < (1e-5 if n >= 1000 else 5e-5), f"{tag}: relative L2 error {l2}"
         if tainted.any():
             g, w = got[tainted], want32[tainted]
             l2 = np.linalg.norm((g - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-300)
-            assert l2 < 1e-2, f"{name} (tainted set): relative L2 error {l2}"
+            worst = float((np.abs(g - w) / (1e-4 * np.abs(w) + 1e-5 * max(np.abs(want32).max(), 1e-300))).max())
+            out["tainted_rel_l2_vs_fp32_oracle"] = float(l2); out["tainted_worst_err_over_tol"] = worst
+            rec[tag] = out
+            assert l2 < 1e-2, f"{tag} (tainted set): relative L2 error {l2}"
 
-    for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb"):
-        check_group(k, inter[k], o64.get(k), o.get(k))
-    check_group("absgrad", grads["absgrad2d"], o64.get("absgrad"), o.get("absgrad"))
-    check_group("mean2d", grads["mean2d"], o64.get("dL_dmean2d"), o.get("dL_dmean2d"))
-    for k in KEYS:
-        check_group("grad " + k, grads[k], ref64[k], ref32[k])
-    # culled splats get exactly zero rows
     culled = saved["radii"] == 0
-    for k in KEYS:
-        assert not np.any(grads[k][culled]), k
+    oracle_grads = {}
+    for mode in (0, 1):
+        ref64 = {k: v.copy() for k, v in o64.backward(dL, grad_mode=mode).items()}
+        inter64 = {k: o64.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
+        ref32 = {k: v.copy() for k, v in o.backward(dL, grad_mode=mode).items()}
+        inter32 = {k: o.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
+        if not np.array_equal(o64.get("n_contrib")[~frag_any], nc_ref[~frag_any]) or not np.array_equal(o64.get("vals"), o.get("vals")):
+            # fp64 binned differently somewhere (a radius at an integer boundary): the fp32 oracle is the strict reference
+            ref64, inter64 = ref32, inter32
+        oracle_grads[mode] = ref64
+        for variant in ("mm", "reduce"):
+            grads, inter = runs[(mode, variant)]
+            rec = report["runs"].setdefault(f"grad_mode{mode}/{variant}", {})
+            tag = f"[mode {mode}, {variant}] "
+            for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb"):
+                check_group(tag + k, rec, inter[k], inter64[k], inter32[k])
+            check_group(tag + "absgrad", rec, grads["absgrad2d"], inter64["absgrad"], inter32["absgrad"])
+            check_group(tag + "mean2d", rec, grads["mean2d"], inter64["dL_dmean2d"], inter32["dL_dmean2d"])
+            for k in KEYS:
+                check_group(tag + "grad " + k, rec, grads[k], ref64[k], ref32[k])
+            for k in KEYS:       # culled splats get exactly zero rows
+                assert not np.any(grads[k][culled]), k
+    # the size of the ambiguity between the two backward definitions on this scene (fp64 oracle): relative L2 per group
+    report["lineage_vs_true_rel_l2"] = {k: float(np.linalg.norm((oracle_grads[1][k] - oracle_grads[0][k]).ravel()) /
+                                                max(np.linalg.norm(oracle_grads[0][k].ravel()), 1e-300)) for k in KEYS}
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(report) + "\n")
+    except OSError:
+        pass
+    print("parity report:", json.dumps({k: report[k] for k in ("config", "tainted_splat_fraction", "fragile_pixel_fraction", "lineage_vs_true_rel_l2")}))
 
 
 def test_accumulate_two_views(rast, oracle_mod):
