@@ -113,6 +113,10 @@ def main():
                     help="independent views each GPU renders per step (pipelined over two contexts when > 1); gradients accumulate")
     ap.add_argument("--shn-tiled", type=int, default=1,
                     help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
+    ap.add_argument("--bwd-variant", default="reduce", choices=["blocks", "reduce", "mm"],
+                    help="A8 kernel (dvs_set_backward_variant): reduce = default (measured winner); blocks / mm = the measured alternatives")
+    ap.add_argument("--fwd-variant", default="quadrant", choices=["blocks", "quadrant"], help="A7 kernel (dvs_set_forward_variant)")
+    ap.add_argument("--grad-mode", type=int, default=0, help="dvs_opts.grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (same cost)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
     args = ap.parse_args()
@@ -157,6 +161,9 @@ def main():
     # the HBM/latency-bound front of view v+1 (preprocess, sorts) runs under the VALU-bound composite kernels of view v.
     n_ctx = max(1, min(args.contexts, VPS))
     rasts = [Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H) for _ in range(n_ctx)]
+    for r_ in rasts:
+        r_.set_backward_variant(args.bwd_variant)
+        r_.set_forward_variant(args.fwd_variant)
     rast = rasts[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)] if n_ctx > 1 else [torch.cuda.current_stream(dev)]
     tiled = bool(args.shn_tiled)
@@ -200,7 +207,8 @@ def main():
             with torch.cuda.stream(st):
                 if n_ctx > 1 and v < n_ctx:
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
-                img = rasts[c].forward(params, cams[v], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled)
+                img = rasts[c].forward(params, cams[v], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled,
+                                       grad_mode=args.grad_mode)
                 dL = torch.add(neg_targets_scaled[v], img, alpha=inv_P)
                 g = grads
                 if factorised:
@@ -380,7 +388,7 @@ def main():
             "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {VPS} view(s) per GPU per step"
                                    + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,

@@ -78,7 +78,8 @@ struct dvs_ctx {
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
-    int bwd_variant = DVS_BWD_MM;        // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create)
+    int bwd_variant = DVS_BWD_REDUCE;    // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create): the measured winner
+    int fwd_variant = DVS_FWD_QUADRANT;  // which A7 kernel (dvs_set_forward_variant; env DVS_FWD_VARIANT at create)
     // stage timing: `timing` = every stage, synchronising per call (profiling iterations); `probe` = hipEvent pairs around the
     // composite kernels only, never synchronising — they are read back once, so the kernels are timed under the concurrency of
     // the real (pipelined) step
@@ -171,7 +172,8 @@ dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
     if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e, __FILE__, __LINE__); return nullptr; }
     dvs_ctx* c = new dvs_ctx();
     c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h;
-    if (const char* v = getenv("DVS_BWD_VARIANT")) c->bwd_variant = (v[0] == '1' || v[0] == 'r') ? DVS_BWD_REDUCE : DVS_BWD_MM;
+    if (const char* v = getenv("DVS_BWD_VARIANT")) c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_REDUCE;
+    if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
     if (hipMalloc((void**)&c->total_dev, 8) != hipSuccess || hipHostMalloc((void**)&c->total_host, 8, hipHostMallocDefault) != hipSuccess) {
         g_last_error = "dvs_create: hipMalloc failed";
         delete c;
@@ -266,9 +268,14 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     // A7 composite
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
-    HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
-                                   c->splat2d.as<float>(), cam->bg, out_rgb,
-                                   c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
+    if (c->fwd_variant == DVS_FWD_QUADRANT)
+        HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+                                       c->splat2d.as<float>(), cam->bg, out_rgb,
+                                       c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
+    else
+        HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+                                              c->splat2d.as<float>(), cam->bg, out_rgb,
+                                              c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
     if (c->probe) (void)probe_event(c, st);
     size_t e8 = tm.mark(); tm.span("render_fwd", e7, e8);
 
@@ -295,9 +302,13 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cam, cons
     size_t e1 = tm ? tm->mark() : 0;
     if (tm) tm->span("bwd_zero", e0, e1);
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
-    HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
-                                   cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
-                                   c->bwd_variant));
+    if (c->bwd_variant == DVS_BWD_BLOCKS)
+        HIPCHECK(dvs_launch_render_bwd_blocks(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
+                                              cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
+    else
+        HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
+                                       cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
+                                       c->bwd_variant));
     if (c->probe) (void)probe_event(c, st);
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
@@ -420,8 +431,13 @@ int dvs_sh_grad_combine(dvs_ctx* c, void* stream, int n, const float* pos, int s
 }
 
 int dvs_set_backward_variant(dvs_ctx* c, int variant) {
-    if (!c || (variant != DVS_BWD_MM && variant != DVS_BWD_REDUCE)) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
+    if (!c || (variant != DVS_BWD_BLOCKS && variant != DVS_BWD_MM && variant != DVS_BWD_REDUCE)) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
     c->bwd_variant = variant;
+    return DVS_OK;
+}
+int dvs_set_forward_variant(dvs_ctx* c, int variant) {
+    if (!c || (variant != DVS_FWD_BLOCKS && variant != DVS_FWD_QUADRANT)) { g_last_error = "dvs_set_forward_variant: bad argument"; return DVS_ERR_INVALID; }
+    c->fwd_variant = variant;
     return DVS_OK;
 }
 

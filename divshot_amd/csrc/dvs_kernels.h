@@ -51,4 +51,15 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
                                  const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad, int grad_mode,
                                  int variant /*DVS_BWD_*: which A8 kernel*/);
 // A8 kernel variants (dvs_set_backward_variant): same inputs, same 48-B row contract, results equal to fp32 roundoff
-enum { DVS_BWD_MM = 0 /*per-splat sums contracted on the fp32 matrix pipe (default)*/, DVS_BWD_REDUCE = 1 /*cross-lane reduction tree per visit*/ };
+enum { DVS_BWD_BLOCKS = 0 /*per-4x4-block lists, four cursors per wave (experiment)*/, DVS_BWD_REDUCE = 1 /*per-quadrant masks, wave-wide
+       reduction tree per visit (default: the measured winner)*/, DVS_BWD_MM = 2 /*per-quadrant masks, sums contracted on the fp32 matrix pipe (experiment)*/ };
+// A7 kernel variants (dvs_set_forward_variant): bit-identical results
+enum { DVS_FWD_BLOCKS = 0 /*per-4x4-block lists (experiment)*/, DVS_FWD_QUADRANT = 1 /*per-quadrant masks walked by the scalar unit (default)*/ };
+
+// render_blocks.hip
+hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
+                                        const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color,
+                                        float* final_T, uint32_t* n_contrib);
+hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
+                                        const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T,
+                                        const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode);

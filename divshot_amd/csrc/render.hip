@@ -12,62 +12,10 @@
 // caps alpha at 0.999; the trainer constant fixed by this build is 0.99, SURVEY.md §8(a) A-notes),
 // blend order renderer/gaussian.cpp:440, 16x16 groups gaussian_common.hlsl:162-163, abs-grad flag
 // application/diverseshot-cli/source/main.cpp:44.
+#include <cstdlib>
 #include "dvs_device.h"
 #include "dvs_kernels.h"
-
-#define RB 256
-
-// blockIdx -> tile: consecutive workgroups land on different XCDs (b % 8), so give each XCD a
-// contiguous band of tiles; neighbouring tiles share splats and therefore L2 lines.
-__device__ __forceinline__ int tile_of_block(int b, int num_tiles) {
-    const int chunk = (num_tiles + 7) >> 3;
-    return (b & 7) * chunk + (b >> 3);
-}
-
-// 12 per-lane partials -> 12 wave totals in 9 VALU swaps + 12 LDS-crossbar swizzles (a plain DPP tree needs 6 DPP adds per value).
-// Two halving steps with the gfx950 swap instructions fold the 64 lanes to 16 while packing 4 values per
-// register (v_permlane32_swap: lanes 32-63 of A <-> lanes 0-31 of B; v_permlane16_swap: odd 16-lane rows of
-// A <-> even rows of B), then a 4-step butterfly (ds_swizzle, see row_sum) finishes inside each 16-lane row.
-// Result: q[k] holds, in every lane of row r, the total of value index kRowValue[k][r]:
-//   q[0] rows -> v0,v2,v1,v3   q[1] rows -> v4,v6,v5,v7   q[2] rows -> v8,v10,v9,v11
-__device__ __forceinline__ float swap32_add(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float swap16_add(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// 16-lane butterfly through ds_swizzle_b32 (the LDS crossbar; no LDS memory is touched) + a plain v_add per stage: the
-// lane exchange leaves the VALU, which is the unit the backward kernel is bound by (a DPP add costs two VALU slots;
-// measured -9 % kernel time against the DPP butterfly). Every lane of a row ends with the row total.
-__device__ __forceinline__ float row_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (1 << 10) | 0x1f));     // xor 1
-    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (2 << 10) | 0x1f));     // xor 2
-    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (4 << 10) | 0x1f));     // xor 4
-    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (8 << 10) | 0x1f));     // xor 8
-    return v;
-}
-// NV = number of live values (11 with abs-grad, 9 without). The odd value out has no partner to be packed with: instead of a
-// swap against a zero register (v_mov + v_permlane32_swap + v_add = 5 issue slots) it is folded across the two wave halves with
-// ds_bpermute_b32 (lane ^ 32; LDS crossbar) + one v_add; both halves then hold the folded value, which only puts a duplicate into
-// a row no lane publishes. `xaddr` = (lane ^ 32) * 4.
-template <int NV>
-__device__ __forceinline__ void wave_reduce12(const float v[12], float q[3], int xaddr) {
-    const float h0 = swap32_add(v[0], v[1]), h1 = swap32_add(v[2], v[3]), h2 = swap32_add(v[4], v[5]);
-    const float h3 = swap32_add(v[6], v[7]);
-    float h4, h5;
-    if (NV == 11) {
-        h4 = swap32_add(v[8], v[9]);
-        h5 = v[10] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[10])));
-    } else {                                                   // 9 values: v[8] is the odd one, the sixth register is empty
-        h4 = v[8] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[8])));
-        h5 = 0.f;
-    }
-    q[0] = row_sum(swap16_add(h0, h1));
-    q[1] = row_sum(swap16_add(h2, h3));
-    q[2] = row_sum(swap16_add(h4, h5));
-}
+#include "render_common.h"
 
 // ---- batch staging + per-quadrant culling masks -------------------------------------------------------
 // Lane t of the workgroup gathers splat t of the batch into LDS and tests the ellipse on which the splat reaches
@@ -343,7 +291,7 @@ __global__ void __launch_bounds__(RB)
 k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
                 const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
-                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage) {
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage, int dbg) {
     __shared__ BatchLds L;
     __shared__ uint32_t s_max[RB / 64];
     __shared__ __attribute__((aligned(16))) float2 s_pair[RB / 64][MM_SLOTS * MM_STRIDE];   // per wave: [slot][pixel] (v5, w); epilogue scratch
@@ -392,6 +340,7 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 
     // phase B + epilogue for the `count` filled rows; jv: lane s (< 16) holds the batch index of row s
     auto flush = [&](int count, uint32_t jv) {
+        if (dbg & 1) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -407,6 +356,7 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
         }
         f32x4 accv = {0.f, 0.f, 0.f, 0.f}, accw = accv, acc1 = accv, acc2 = accv;
         const float2* rp = pairp + sl * MM_STRIDE + kq;
+        if (!(dbg & 2))
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float2 vw = rp[4 * s];
@@ -519,7 +469,7 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
                 // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE: it passes as if alpha = opacity * G
                 const bool gate = contrib && (lineage || !(oa > DVS_ALPHA_MAX));
                 const float v5 = gate ? G * dL_dalpha : 0.f;
-                pairp[slot * MM_STRIDE + lane] = make_float2(v5, w);
+                if (!(dbg & 4)) pairp[slot * MM_STRIDE + lane] = make_float2(v5, w);
                 // lane `slot` of jvec = j (both wave-uniform; one SGPR per VALU instruction on gfx9, so the lane select goes through m0)
                 asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(jvec) : "s"(j), "s"(slot) : "m0");
                 if (++slot == MM_SLOTS) { flush(MM_SLOTS, jvec); slot = 0; }
@@ -549,11 +499,15 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
-#define DVS_RB(KERNEL)                                                                                                          \
-    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,        \
-                       (const float4*)splat2d, bg[0], bg[1], bg[2], final_T, n_contrib, dL_dout, grad_rows, lineage)
+    // experiment knobs (tools/bwd_probe.py): extra dynamic LDS to lower the occupancy, debug bits that drop parts of the mm kernel
+    const char* e_lds = getenv("DVS_BWD_EXTRA_LDS"); const char* e_dbg = getenv("DVS_MM_DEBUG");
+    const size_t extra_lds = e_lds ? (size_t)atoi(e_lds) : 0;
+    const int dbg = e_dbg ? atoi(e_dbg) : 0;
+#define DVS_RB(KERNEL, ...)                                                                                                          \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,        \
+                       (const float4*)splat2d, bg[0], bg[1], bg[2], final_T, n_contrib, dL_dout, grad_rows, lineage, ##__VA_ARGS__)
     if (variant == DVS_BWD_REDUCE) { if (absgrad) DVS_RB(k_render_bwd<true>); else DVS_RB(k_render_bwd<false>); }
-    else { if (absgrad) DVS_RB(k_render_bwd_mm<true>); else DVS_RB(k_render_bwd_mm<false>); }
+    else { if (absgrad) DVS_RB(k_render_bwd_mm<true>, dbg); else DVS_RB(k_render_bwd_mm<false>, dbg); }
 #undef DVS_RB
     return hipGetLastError();
 }

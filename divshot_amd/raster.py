@@ -83,9 +83,14 @@ class Rasterizer:
         check(lib.dvs_keep_bwd_intermediates(self.ctx, 1 if on else 0))
 
     def set_backward_variant(self, variant):
-        """A8 kernel: 0 / "mm" = sums contracted on the fp32 matrix pipe (default), 1 / "reduce" = cross-lane reduction per visit."""
-        v = {"mm": 0, "reduce": 1}.get(variant, variant)
+        """A8 kernel: 1 / "reduce" (default), 0 / "blocks", 2 / "mm" (experiments) — see dvs_raster.h."""
+        v = {"blocks": 0, "reduce": 1, "mm": 2}.get(variant, variant)
         check(lib.dvs_set_backward_variant(self.ctx, int(v)), "dvs_set_backward_variant")
+
+    def set_forward_variant(self, variant):
+        """A7 kernel: 1 / "quadrant" (default), 0 / "blocks" (experiment); bit-identical results."""
+        v = {"blocks": 0, "quadrant": 1}.get(variant, variant)
+        check(lib.dvs_set_forward_variant(self.ctx, int(v)), "dvs_set_forward_variant")
 
     def enable_timing(self, on=True):
         check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))

@@ -189,11 +189,17 @@ int dvs_sh_grad_combine(dvs_ctx* ctx, void* stream, int n, const float* pos, int
 /* Convert an shN array (DEVICE, src != dst) between DVS_SHN_ROWS [n*45] and DVS_SHN_TILED [ceil(n/64)*64*48]. */
 int dvs_shn_relayout(dvs_ctx* ctx, void* stream, int n, const float* src, float* dst, int to_tiled);
 
-/* The composite backward (A8) exists in two kernels with the same inputs and the same output rows (equal to fp32 roundoff):
- *   0 "mm"     (default) per-pixel recurrence, per-splat sums contracted on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
- *   1 "reduce" per-pixel recurrence, a 12-value cross-lane reduction tree per (wave, splat) visit (the round-1 kernel)
- * The environment variable DVS_BWD_VARIANT (0/1) sets the default of new contexts. */
+/* The composite kernels exist in several variants with the same inputs and outputs, kept selectable so that the measured
+ * comparison can be repeated (all of them pass the same parity tests). Backward (A8), results equal to fp32 roundoff:
+ *   1 "reduce"  (default, the measured winner) per-8x8-quadrant cull masks, a 12-value wave-wide reduction tree per (wave, splat) visit
+ *   0 "blocks"  per-4x4-pixel-block splat lists built while a batch is staged; the four 16-lane groups of a wave walk four different
+ *               lists; group totals merged in LDS. Fewer vector instructions, but bound by the LDS float atomics (ds_add_f32)
+ *   2 "mm"      per-quadrant masks, the per-splat sums contracted on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); bound by its
+ *               LDS footprint (3 workgroups per CU) and by the matrix and vector pipes not overlapping
+ * Forward (A7), bit-identical results:  1 "quadrant" (default) / 0 "blocks".
+ * The environment variables DVS_BWD_VARIANT / DVS_FWD_VARIANT (digits) set the defaults of new contexts. */
 int dvs_set_backward_variant(dvs_ctx* ctx, int variant);
+int dvs_set_forward_variant(dvs_ctx* ctx, int variant);
 
 /* Stage-level entry points (used by the parity tests and the profiler harness). */
 /* radix sort of (u32 key, u32 value) pairs over key bits [bit_lo, bit_hi), stable, LSD, 8-bit digits.

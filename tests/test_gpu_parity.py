@@ -59,25 +59,34 @@ def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
     import torch
     from divshot_amd.raster import params_to_device
     Pd = params_to_device(P, rast.tdev)
+    # the two A7 kernels are bit-identical (same per-pixel sequence of contributing splats, same expressions)
+    rast.set_forward_variant("blocks")
+    img_q = rast.forward(Pd, cam, sh_degree=deg, antialias=aa, absgrad=absgrad).clone()
+    torch.cuda.synchronize()
+    saved_q = rast.saved()
+    rast.set_forward_variant("quadrant")
     img = rast.forward(Pd, cam, sh_degree=deg, antialias=aa, absgrad=absgrad)
     torch.cuda.synchronize()
     img_h = img.cpu().numpy()
     saved = rast.saved()
+    assert torch.equal(img, img_q), "A7 variants differ in the image"
+    assert np.array_equal(saved["final_T"].view(np.uint32), saved_q["final_T"].view(np.uint32)) and np.array_equal(saved["n_contrib"], saved_q["n_contrib"])
     keys = rast.sorted_keys()
     dL = torch.from_numpy((img_h - tgt) / tgt[0].size).to(rast.tdev)
     runs = {}
     for mode in (0, 1):
-        for variant in ("mm", "reduce"):
+        for variant in BWD_VARIANTS:
             rast.set_backward_variant(variant)
             rast._opts.grad_mode = mode
             grads = rast.backward(dL, want_mean2d=True)
             torch.cuda.synchronize()
             runs[(mode, variant)] = ({k: v.cpu().numpy() for k, v in grads.items()}, rast.bwd_intermediates())
-    rast.set_backward_variant("mm")
+    rast.set_backward_variant("reduce")
     rast._opts.grad_mode = 0
     return img_h, saved, keys, runs, (img_h - tgt) / tgt[0].size
 
 
+BWD_VARIANTS = ("reduce", "blocks", "mm")
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 
@@ -180,7 +189,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
             # fp64 binned differently somewhere (a radius at an integer boundary): the fp32 oracle is the strict reference
             ref64, inter64 = ref32, inter32
         oracle_grads[mode] = ref64
-        for variant in ("mm", "reduce"):
+        for variant in BWD_VARIANTS:
             grads, inter = runs[(mode, variant)]
             rec = report["runs"].setdefault(f"grad_mode{mode}/{variant}", {})
             tag = f"[mode {mode}, {variant}] "
