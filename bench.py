@@ -3,13 +3,14 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
-A step = one pass of the hot path over one batch: every rank renders --views-per-step (default 8 = the "8 synthetic cams/iter" of BASELINE config C4) independent synthetic
-views of the replicated 1M-splat scene (A2..A7), forms dL/drgb = (rgb - target)/P and runs the backward (A8, A9) for each,
-accumulating the gradient rows; the views of a step are software-pipelined over two rasterizer contexts / HIP streams
-(steps do not overlap). For N>1 the step ends by exchanging the 59-float gradient rows over xGMI: by default the factorised exchange of
-divshot_amd/parallel.py (all-reduce of the 11 geometry floats + all-gather of the 3-float colour gradients, SH rows rebuilt
-locally; 56 B/splat on the wire instead of 236), or with --exchange allreduce one sum-all-reduce of all rows.
-value = N * views_per_step * K / time  (weak scaling: per-GPU work is fixed).
+A step = one training iteration's pass of the hot path over one batch of views = BASELINE.json config C4: 8 synthetic cameras per
+iteration over the replicated 1M-splat scene, SHARDED over the GPUs (8/N views per GPU: rank r renders views r, r+N, ...), i.e.
+strong scaling: the work of a step is fixed as N grows. Per view: A2..A7, dL/drgb = (rgb - target)/P, A8, A9, gradient rows
+accumulated over the rank's views; the views of a rank are software-pipelined over two rasterizer contexts / HIP streams (steps do
+not overlap). For N>1 the step ends by exchanging the 59-float gradient rows over xGMI: by default the
+factorised exchange of divshot_amd/parallel.py (all-reduce of the 11 geometry floats + all-gather of the 3-float colour gradients,
+SH rows rebuilt locally; 56 B/splat on the wire instead of 236), or with --exchange allreduce one sum-all-reduce of all rows.
+value = 8 * K / time (whole job). `--views-per-step V` instead fixes V views per GPU per step (weak scaling, the round-1 shape).
 Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
@@ -47,6 +48,37 @@ def algorithmic_bytes(N, V, T, P, tiles, sh_degree, absgrad):
         "render_bwd": 76 * T + 20 * P + (8 * T if absgrad else 0),
         "preprocess_bwd": (44 + B_sh + 36 + 48) * V + (44 + B_sh) * N,
     }, p
+
+
+def read_clocks(dev_index=0):
+    """Current shader / memory clock of the device (MHz) as the driver reports them: sysfs pp_dpm_* (the line marked '*'), else
+    rocm-smi. SURVEY.md §8(d): 'clocks as found, report sclk/mclk'. Returns None entries when neither source is readable."""
+    import glob, re, subprocess
+    out = {"sclk_mhz": None, "mclk_mhz": None, "source": None}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            card = os.path.dirname(cards[min(dev_index, len(cards) - 1)])
+            for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+                for line in open(os.path.join(card, fn)):
+                    if "*" in line:
+                        m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                        if m:
+                            out[key] = int(m.group(1))
+            out["source"] = "sysfs pp_dpm_sclk / pp_dpm_mclk (current level, read right after the timed region)"
+    except Exception:      # noqa: BLE001
+        pass
+    if out["sclk_mhz"] is None:
+        try:
+            txt = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+            for key, tag in (("sclk_mhz", "sclk"), ("mclk_mhz", "mclk")):
+                m = re.search(tag + r" clock level.*?\((\d+)Mhz\)", txt, re.I)
+                if m:
+                    out[key] = int(m.group(1))
+            out["source"] = "rocm-smi --showclocks"
+        except Exception:      # noqa: BLE001
+            pass
+    return out
 
 
 def cpu_baseline(workload, max_seconds=60.0):
@@ -101,16 +133,17 @@ cpu_baseline.reference = None
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)       # 20 warm-up + 200 timed iterations
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
     ap.add_argument("--contexts", type=int, default=2, help="rasterizer contexts / HIP streams the views of a step are pipelined over")
     ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
                     help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
                          "12 B per splat per view, SH rows rebuilt locally, gathers overlapped with compute); auto = factorised")
-    ap.add_argument("--views-per-step", type=int, default=8,
-                    help="independent views each GPU renders per step (pipelined over two contexts when > 1); gradients accumulate")
+    ap.add_argument("--global-views", type=int, default=8, help="views per training iteration, sharded over the GPUs (BASELINE config C4: 8)")
+    ap.add_argument("--views-per-step", type=int, default=0,
+                    help="if > 0: this many views PER GPU per step instead of sharding --global-views (weak scaling, the round-1 shape)")
     ap.add_argument("--shn-tiled", type=int, default=1,
                     help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
     ap.add_argument("--bwd-variant", default="reduce", choices=["blocks", "reduce", "mm"],
@@ -148,11 +181,22 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     n, W, H, deg, soff = WORKLOADS[args.workload]
-    VPS = max(1, args.views_per_step)             # views each rank renders per step (its share of the iteration's batch)
-    n_cams = max(8, world * VPS)
+    weak = args.views_per_step > 0
+    if weak:                                      # V views per GPU per step
+        VPS = args.views_per_step
+        n_cams = max(8, world * VPS)
+        my_views = [(rank * VPS + v) % n_cams for v in range(VPS)]
+        views_of = lambda r: [(r * VPS + v) % n_cams for v in range(VPS)]
+    else:                                         # config C4: one iteration = --global-views views, view g on rank g % world
+        if args.global_views % world != 0:
+            raise SystemExit(f"bench.py: --global-views {args.global_views} must be a multiple of the number of GPUs ({world})")
+        VPS = args.global_views // world
+        n_cams = max(8, args.global_views)
+        views_of = lambda r: list(range(r, args.global_views, world))
+        my_views = views_of(rank)
+    GLOBAL_VIEWS = world * VPS                    # views per step over all ranks
     spec = dv.make_spec(n, W, H, sh_degree=deg, n_cams=n_cams, scale_log_offset=soff)
     P = dv.synth_splats(spec)                     # identical replica on every rank (same seed)
-    my_views = [(rank * VPS + v) % n_cams for v in range(VPS)]      # rank r renders views r*VPS .. r*VPS+VPS-1
     cams = [dv.synth_camera(spec, i) for i in my_views]
     targets = [torch.from_numpy(dv.synth_target(spec, i)).to(dev) for i in my_views]
     cam, target = cams[0], targets[0]
@@ -190,16 +234,17 @@ def main():
     factorised = dist is not None and exchange == "factorised"
     if factorised:
         fx = FactorisedExchange(n, dev, world, views_per_rank=VPS)
-        campos_all = np.array([list(dv.synth_camera(spec, (r * VPS + v) % n_cams).campos) for r, v in fx.slots()], np.float32)
+        campos_all = np.array([list(dv.synth_camera(spec, views_of(r)[v]).campos) for r, v in fx.slots()], np.float32)
         # rebuild the SH rows of a view's slots right behind its all-gather, on the exchange's side stream
         fx.set_combiner(lambda lo, hi, acc: rast.sh_grad_combine(params["pos"], campos_all[lo:hi], fx.dcolor_all[lo:hi], gbuf.views["sh0"],
                                                                  gbuf.views["shN"], deg, accumulate=acc, shn_tiled=tiled))
     bwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
     step_done = torch.cuda.Event()
     main_stream = torch.cuda.current_stream(dev)
+    comm_marks = []                               # (event before the exposed exchange, event after it) per timed step
     torch.cuda.synchronize()
 
-    def step():
+    def step(timed=False):
         step_done.record(main_stream)              # everything enqueued so far (previous step incl. its exchange)
         for v in range(VPS):
             c = v % n_ctx
@@ -225,22 +270,19 @@ def main():
                     fx.gather_view(v, bwd_done[c] if n_ctx > 1 else None)      # overlaps with the next view's kernels
         if n_ctx > 1:
             main_stream.wait_event(bwd_done[(VPS - 1) % n_ctx])
-        if factorised:
-            fx.exchange(gbuf, rast, params["pos"], campos_all, deg, shn_tiled=tiled)
-        elif dist is not None:
-            dist.all_reduce(flat)
+        if dist is not None:
+            ea = None
+            if timed:
+                ea = torch.cuda.Event(enable_timing=True); ea.record(main_stream)
+            if factorised:
+                fx.exchange(gbuf, rast, params["pos"], campos_all, deg, shn_tiled=tiled)
+            else:
+                dist.all_reduce(flat)
+            if timed:
+                eb = torch.cuda.Event(enable_timing=True); eb.record(main_stream)
+                comm_marks.append((ea, eb))
 
-    if factorised:
-        # The factorised exchange drives RCCL from a side stream; if this stack refuses that (API/driver differences between
-        # boxes), fall back to the plain all-reduce of the full rows instead of losing the measurement. Every rank sees the same error.
-        try:
-            step()
-            torch.cuda.synchronize()
-        except Exception as e:      # noqa: BLE001
-            if rank == 0:
-                print(f"bench.py: factorised exchange failed ({type(e).__name__}: {e}); falling back to --exchange allreduce", file=sys.stderr)
-            factorised = False
-            exchange = "allreduce (fallback)"
+    # (no fallback: if the exchange cannot run on this stack the bench fails loudly instead of measuring something else)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -253,7 +295,7 @@ def main():
     t0 = time.perf_counter()
     for i_ in range(args.steps):
         marks[i_].record(main_stream)
-        step()
+        step(timed=True)
     marks[args.steps].record(main_stream)
     torch.cuda.synchronize()
     if dist is not None:
@@ -267,6 +309,24 @@ def main():
 
     grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
                                                                                    # (taken before the profiling iterations reuse the buffer)
+    # ---- strict single-view figure of SURVEY.md §8(d): 1 / (t_fwd + t_bwd), one view at a time on one stream, no pipelining ----
+    strict = None
+    if rank == 0 and args.profile_iters > 0:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_strict = max(10, min(100, args.steps))
+        g_strict = {k: v for k, v in grads.items() if k != "dcolor"}
+        for it_ in range(n_strict + 5):
+            if it_ == 5:
+                ev0.record(main_stream)
+            img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode)
+            dL = torch.add(neg_targets_scaled[0], img, alpha=inv_P)
+            rast.backward(dL, grads=g_strict)
+        ev1.record(main_stream)
+        torch.cuda.synchronize()
+        ms_view = ev0.elapsed_time(ev1) / n_strict
+        strict = {"ms_per_view": ms_view, "views_per_s": 1e3 / ms_view, "views": n_strict,
+                  "note": "one view at a time on one stream (forward incl. its host sync on T, upstream gradient, backward); hipEvents"}
+    clocks = read_clocks(dev_index) if rank == 0 else None
     # ---- the composite kernels timed inside the real step: a replica of the timed region with hipEvent pairs around k_render_fwd /
     # k_render_bwd on the streams they are launched on, never synchronised in between (dvs_enable_kernel_probe). Same concurrency as
     # the timed region (views pipelined over two streams), so these are the durations rocprofv3 sees for the same command.
@@ -319,7 +379,13 @@ def main():
             device_info = None
         step_ms = sorted(marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(args.steps))
         step_spread = [step_ms[int(q * (len(step_ms) - 1))] for q in (0.1, 0.5, 0.9)] if step_ms else None
-        value = world * VPS * args.steps / elapsed
+        value = GLOBAL_VIEWS * args.steps / elapsed
+        comm_ms = None
+        if comm_marks:
+            cm = sorted(a_.elapsed_time(b_) for a_, b_ in comm_marks)
+            comm_ms = {"mean": float(np.mean(cm)), "p50": cm[len(cm) // 2], "p90": cm[int(0.9 * (len(cm) - 1))],
+                       "note": "rank 0, main stream: from 'last view's backward done' to 'exchange complete' (the gathers of earlier views "
+                               "run under compute and are not in this figure)"}
         # dominant kernel = the longest single-kernel stage
         single = {k: stage_ms[k] for k in ("render_bwd", "render_fwd", "preprocess_fwd", "preprocess_bwd", "duplicate") if k in stage_ms}
         roofline = None
@@ -381,11 +447,14 @@ def main():
         rec = {
             "metric": "train views/sec (fwd+bwd raster) at 1M splats 1920x1080" if args.workload == "C3" else f"train views/sec (fwd+bwd raster), workload {args.workload}",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+            "strict_single_view": strict, "t_raster_ms_per_step": (ms_per_step - comm_ms["mean"]) if comm_ms else ms_per_step,
+            "t_comm_exposed_ms_per_step": comm_ms, "clocks": clocks,
             "step_ms_p10_p50_p90": step_spread,
             "device": device_info,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {VPS} view(s) per GPU per step"
+            "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {GLOBAL_VIEWS} views per iteration "
+                                   + ("(weak scaling: fixed per GPU), " if weak else f"sharded over {world} GPU(s) (BASELINE config C4), ") + f"{VPS} view(s) per GPU per step"
                                    + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
                        "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",

@@ -7,7 +7,14 @@ all six parameter groups live in ONE flat fp32 buffer so the exchange is a singl
 on MI355X's point-to-point xGMI mesh a few large messages use the links far better than many small ones.
 Backend: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
 """
+import os
 import torch
+
+# DVS_FORCE_COLLECTIVES=1: issue every collective even in a 1-rank group (RCCL allows a 1-rank communicator) — lets a single-GPU
+# box prove librccl loading, communicator creation and the side-stream collectives before the first multi-GPU run
+def _force():
+    return os.environ.get("DVS_FORCE_COLLECTIVES", "0") == "1"
+
 
 PARAM_KEYS = ("pos", "sh0", "shN", "opacity", "scale", "rot")
 PARAM_WIDTH = {"pos": 3, "sh0": 3, "shN": 45, "opacity": 1, "scale": 3, "rot": 4}
@@ -44,7 +51,7 @@ class GradBuffer:
     def all_reduce(self, group=None, average=False):
         """Sum (or mean) ALL gradient rows over all ranks (236 B/splat on the wire). No-op without a process group."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _force()):
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
@@ -91,7 +98,7 @@ class FactorisedExchange:
     def _gather(self, v, group):
         import torch.distributed as dist
         out = self.dcolor_all[v * self.world:(v + 1) * self.world]
-        if self.world == 1:
+        if self.world == 1 and not (_force() and dist.is_initialized()):
             out[0].copy_(self.dcolor_local[v])
             return
         try:
@@ -128,7 +135,7 @@ class FactorisedExchange:
                 self.gather_view(v, None, group)
         self._gathered = [False] * self.views_per_rank
         self._n_combined = 0
-        if self.world > 1:
+        if self.world > 1 or (_force() and dist.is_initialized()):
             dist.all_reduce(gbuf.flat_geom, op=dist.ReduceOp.SUM, group=group)
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
@@ -183,7 +190,7 @@ class ShardedAdam:
         if self._gpad is not None:
             self._gpad[: grads_flat.numel()].copy_(grads_flat)
             src = self._gpad
-        if self.world == 1:
+        if self.world == 1 and not (_force() and dist.is_initialized()):
             self.gshard.copy_(src[: self.shard])
             return
         try:
@@ -217,7 +224,7 @@ class ShardedAdam:
         self._reduce_scatter(grads_flat)
         self.pshard[: self.hi - self.lo].copy_(self.p[self.lo:self.hi])
         self._adam(lr_scale)
-        if self.world == 1:
+        if self.world == 1 and not (_force() and dist.is_initialized()):
             self.p.copy_(self.pshard[:n])
             return
         dst = self._ppad if self._ppad is not None else self.p

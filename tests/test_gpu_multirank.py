@@ -46,3 +46,69 @@ def test_pipelined_views_accumulate_like_sequential(gpu_device):
     g4 = run(4)["grad_l2_after_exchange"]
     g1 = run(1)["grad_l2_after_exchange"]
     assert g4["pos"] > 1.2 * g1["pos"]            # four different views accumulated, not one
+
+
+def test_rccl_one_rank_communicator(gpu_device):
+    """Backend "nccl" (= RCCL on ROCm) for real, on the one GPU this box has: a 1-rank communicator runs every collective the
+    multi-GPU step uses — all_reduce of the flat gradient buffer, all_gather_into_tensor on the exchange's side stream behind a
+    backward, the geometry all-reduce, reduce_scatter_tensor / all_gather_into_tensor of ShardedAdam — so that librccl loading,
+    communicator creation and the stream semantics are proven on hardware before the first 8-GPU run.
+    With one rank every collective is the identity, so the results must equal the single-process step."""
+    code = r"""
+import os, sys, json, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DVS_ROOT"])
+os.environ["DVS_FORCE_COLLECTIVES"] = "1"
+import divshot_amd as dv
+from divshot_amd.raster import Rasterizer, params_to_device
+from divshot_amd.parallel import GradBuffer, FactorisedExchange, ShardedAdam, PARAM_WIDTH, FLAT_ORDER
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+n, W, H = 20000, 320, 200
+spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=2)
+P = params_to_device(dv.synth_splats(spec), dev)
+r = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+cams = [dv.synth_camera(spec, i) for i in range(2)]
+tg = [torch.from_numpy(dv.synth_target(spec, i)).to(dev) for i in range(2)]
+# reference: plain accumulation of the two views, no process-group involvement
+ref = None
+for v in range(2):
+    img = r.forward(P, cams[v], sh_degree=3)
+    ref = r.backward(((img - tg[v]) / (W * H)).contiguous(), grads=ref, accumulate=ref is not None)
+ref = {k: t.clone() for k, t in ref.items()}
+# the step as bench.py runs it, through RCCL: factorised exchange with the early gather on the side stream
+gb = GradBuffer(n, dev); fx = FactorisedExchange(n, dev, 1, views_per_rank=2)
+campos = np.array([list(c.campos) for c in cams], np.float32)
+done = torch.cuda.Event()
+for v in range(2):
+    img = r.forward(P, cams[v], sh_degree=3)
+    g = dict(gb.views); g["dcolor"] = fx.dcolor_local[v]
+    r.backward(((img - tg[v]) / (W * H)).contiguous(), grads=g, accumulate=(v > 0), factorised_sh=True)
+    done.record()
+    if v == 0:
+        fx.gather_view(0, done)
+fx.exchange(gb, r, P["pos"], campos, 3)
+torch.cuda.synchronize()
+err = {k: float((gb.views[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)) for k in ("pos", "sh0", "shN", "opacity", "scale", "rot")}
+# plain all-reduce of the full rows
+flat_before = gb.flat.clone(); gb.all_reduce(); torch.cuda.synchronize()
+err["allreduce_identity"] = float((gb.flat - flat_before).abs().max())
+# ShardedAdam: reduce_scatter -> Adam on the shard -> all_gather, against a second instance that skips the collectives
+sizes = [n * PARAM_WIDTH[k] for k in FLAT_ORDER]; lrs = [1e-3] * len(sizes)
+p1 = torch.randn(sum(sizes), device=dev); p2 = p1.clone()
+a1 = ShardedAdam(p1, sizes, lrs, 1, 0); a1.step(gb.flat)
+os.environ["DVS_FORCE_COLLECTIVES"] = "0"
+a2 = ShardedAdam(p2, sizes, lrs, 1, 0); a2.step(gb.flat)
+torch.cuda.synchronize()
+err["sharded_adam"] = float((p1 - p2).abs().max())
+print("RESULT " + json.dumps({"err": err, "backend": dist.get_backend(), "nccl_version": list(torch.cuda.nccl.version())}))
+dist.destroy_process_group()
+"""
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DVS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["backend"] == "nccl"
+    for k, v in res["err"].items():
+        assert v <= (0.0 if k in ("allreduce_identity", "sharded_adam") else 2e-4), (k, v, res)
