@@ -150,6 +150,7 @@ def main():
                     help="A8 kernel (dvs_set_backward_variant): reduce = default (measured winner); blocks / mm = the measured alternatives")
     ap.add_argument("--fwd-variant", default="quadrant", choices=["blocks", "quadrant"], help="A7 kernel (dvs_set_forward_variant)")
     ap.add_argument("--grad-mode", type=int, default=0, help="dvs_opts.grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (same cost)")
+    ap.add_argument("--async-forward", type=int, default=1, help="1: dvs_set_async — the forward never synchronises the host (T stays on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
     args = ap.parse_args()
@@ -208,6 +209,7 @@ def main():
     for r_ in rasts:
         r_.set_backward_variant(args.bwd_variant)
         r_.set_forward_variant(args.fwd_variant)
+        r_.set_async(bool(args.async_forward))
     rast = rasts[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)] if n_ctx > 1 else [torch.cuda.current_stream(dev)]
     tiled = bool(args.shn_tiled)
@@ -364,7 +366,7 @@ def main():
     if rank == 0:
         st = rast.state
         V = int((torch.from_numpy(rast._d2h(st.radii, (n,), np.int32)) > 0).sum())
-        T = int(st.num_rendered)
+        T = int(rast.get_num_rendered())          # (synchronises; also raises on an instance-arena overflow during the run)
         Ppix = W * H
         tiles = st.tiles_x * st.tiles_y
         ab, p = algorithmic_bytes(n, V, T, Ppix, tiles, deg, bool(args.absgrad))
@@ -457,7 +459,7 @@ def main():
                                    + ("(weak scaling: fixed per GPU), " if weak else f"sharded over {world} GPU(s) (BASELINE config C4), ") + f"{VPS} view(s) per GPU per step"
                                    + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "async_forward": bool(args.async_forward), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,
@@ -495,7 +497,7 @@ def main():
                     ok = ~ref["fragile"]
                     ih = img_g.cpu().numpy()
                     err = np.abs(ih[:, ok] - ref["img"][:, ok]) / (1e-4 * np.abs(ref["img"][:, ok]) + 1e-6)
-                    par = {"view": 0, "num_rendered_equal": int(rast.num_rendered) == ref["num_rendered"],
+                    par = {"view": 0, "num_rendered_equal": int(rast.get_num_rendered()) == ref["num_rendered"],
                            "rgb_max_err_over_tol(1e-4 rel + 1e-6)": float(err.max()), "fragile_pixels": int(ref["fragile"].sum())}
                     for k_ in ("pos", "sh0", "opacity", "scale", "rot"):
                         a, b = g1[k_].double().cpu().numpy(), np.asarray(ref["grads"][k_], np.float64)

@@ -83,6 +83,8 @@ _PROTOS = {
     "dvs_export_sorted_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_get_bwd_intermediates": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "dvs_keep_bwd_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_set_async": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_get_num_rendered": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "dvs_set_backward_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_set_forward_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -57,38 +57,46 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 // wave w of block b owns the contiguous items [b*PART + w*64*ITEMS, +64*ITEMS), read in ITEMS rounds of 64.
 template <int SORT_ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t dmask, uint32_t* __restrict__ hist, uint32_t num_blocks) {
+k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n_host, const uint64_t* __restrict__ n_dev, int shift, uint32_t dmask,
+            uint32_t* __restrict__ hist, uint32_t num_blocks) {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX];
-    for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
-    __syncthreads();
+    // device-side count (no host round trip for T): `num_blocks` partitions cover the capacity n_host, the grid may be smaller (sized
+    // for the expected count) — every workgroup strides over the partitions; partitions beyond n only publish zero counts
+    const uint64_t n = n_dev ? (*n_dev < n_host ? *n_dev : n_host) : n_host;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr int SORT_PART = SORT_BLOCK * SORT_ITEMS;
-    const uint64_t wbase = (uint64_t)blockIdx.x * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
-    // all of the lane's keys are requested before the first one is used: with one load per round the kernel is bound by
-    // SORT_ITEMS dependent HBM round trips at 3 waves per SIMD
-    uint32_t kreg[SORT_ITEMS];
+    for (uint32_t part = blockIdx.x; part < num_blocks; part += gridDim.x) {
+        if ((uint64_t)part * SORT_PART >= n) { hist[(uint64_t)threadIdx.x * num_blocks + part] = 0u; continue; }
+        for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
+        __syncthreads();
+        const uint64_t wbase = (uint64_t)part * SORT_PART + (uint64_t)wave * (64 * SORT_ITEMS);
+        // all of the lane's keys are requested before the first one is used: with one load per round the kernel is bound by
+        // SORT_ITEMS dependent HBM round trips at 3 waves per SIMD
+        uint32_t kreg[SORT_ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
-        kreg[r] = idx < n ? keys[idx] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
-        const bool valid = idx < n;
-        const uint32_t d = valid ? ((kreg[r] >> shift) & dmask) : 0u;
-        const uint64_t peers = match_digit(d, valid);
-        if (valid) {
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-            if (below == 0) cnt[wave][d] += (uint32_t)__popcll(peers);
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            kreg[r] = idx < n ? keys[idx] : 0u;
         }
-    }
-    __syncthreads();
-    const uint32_t d = threadIdx.x;
-    uint32_t s = 0;
 #pragma unroll
-    for (int w = 0; w < SORT_WAVES; ++w) s += cnt[w][d];
-    hist[(uint64_t)d * num_blocks + blockIdx.x] = s;
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            const bool valid = idx < n;
+            const uint32_t d = valid ? ((kreg[r] >> shift) & dmask) : 0u;
+            const uint64_t peers = match_digit(d, valid);
+            if (valid) {
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+                if (below == 0) cnt[wave][d] += (uint32_t)__popcll(peers);
+            }
+        }
+        __syncthreads();
+        const uint32_t d = threadIdx.x;
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) s += cnt[w][d];
+        hist[(uint64_t)d * num_blocks + part] = s;
+        __syncthreads();
+    }
 }
 
 // one workgroup per digit: exclusive scan of its row of per-block counts, row total -> totals[d]
@@ -113,76 +121,80 @@ k_sort_rowscan(uint32_t* __restrict__ hist, uint32_t num_blocks, uint32_t* __res
 template <int SORT_ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-               uint32_t* __restrict__ vals_out, uint64_t n, int shift, uint32_t dmask, const uint32_t* __restrict__ hist,
-               const uint32_t* __restrict__ totals, uint32_t num_blocks) {
+               uint32_t* __restrict__ vals_out, uint64_t n_host, const uint64_t* __restrict__ n_dev, int shift, uint32_t dmask,
+               const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, uint32_t num_blocks) {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX];     // per-wave digit counts, then per-wave local bases
     __shared__ uint32_t gdelta[RADIX];              // global destination of LDS slot s with digit d = gdelta[d] + s
     __shared__ uint32_t tmp[SORT_WAVES + 1];
     constexpr int SORT_PART = SORT_BLOCK * SORT_ITEMS;
     __shared__ uint32_t stage_k[SORT_PART];
     __shared__ uint32_t stage_v[SORT_PART];
-    for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
-    __syncthreads();
+    const uint64_t n = n_dev ? (*n_dev < n_host ? *n_dev : n_host) : n_host;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint64_t pbase = (uint64_t)blockIdx.x * SORT_PART;
-    const uint64_t wbase = pbase + (uint64_t)wave * (64 * SORT_ITEMS);
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    for (uint32_t part = blockIdx.x; (uint64_t)part * SORT_PART < n; part += gridDim.x) {       // (uniform per workgroup)
+        for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
+        __syncthreads();
+        const uint64_t pbase = (uint64_t)part * SORT_PART;
+        const uint64_t wbase = pbase + (uint64_t)wave * (64 * SORT_ITEMS);
+        uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
-        const bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[idx] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[r] >> shift) & dmask;
-        const uint64_t peers = match_digit(d, valid);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        uint32_t prev = 0;
-        if (valid) {
-            prev = cnt[wave][d];                                   // in-order LDS: all peers read before the leader writes
-            if (below == 0) cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            const bool valid = idx < n;
+            key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+            val[r] = valid ? vals_in[idx] : 0u;
         }
-        rank[r] = prev + below;
-    }
-    __syncthreads();
-    {
-        const uint32_t d = threadIdx.x;
-        uint32_t c[SORT_WAVES], bc = 0;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) { c[w] = cnt[w][d]; bc += c[w]; }
-        uint32_t tot;
-        const uint32_t loff = block_excl_scan(bc, tmp, &tot);                 // where digit d starts in the LDS stage
-        const uint32_t digit_excl = block_excl_scan(totals[d], tmp, &tot);    // where digit d starts globally
-        gdelta[d] = digit_excl + hist[(uint64_t)d * num_blocks + blockIdx.x] - loff;
-        uint32_t run = loff;
-#pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) { cnt[w][d] = run; run += c[w]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
-        if (idx < n) {
-            const uint32_t pos = cnt[wave][(key[r] >> shift) & dmask] + rank[r];
-            stage_k[pos] = key[r];
-            stage_v[pos] = val[r];
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            const bool valid = idx < n;
+            const uint32_t d = (key[r] >> shift) & dmask;
+            const uint64_t peers = match_digit(d, valid);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            uint32_t prev = 0;
+            if (valid) {
+                prev = cnt[wave][d];                                   // in-order LDS: all peers read before the leader writes
+                if (below == 0) cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+            }
+            rank[r] = prev + below;
         }
-    }
-    __syncthreads();
-    const uint32_t nvalid = (uint32_t)((n - pbase) < (uint64_t)SORT_PART ? (n - pbase) : (uint64_t)SORT_PART);
+        __syncthreads();
+        {
+            const uint32_t d = threadIdx.x;
+            uint32_t c[SORT_WAVES], bc = 0;
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const uint32_t slot = (uint32_t)i * SORT_BLOCK + threadIdx.x;
-        if (slot < nvalid) {
-            const uint32_t k = stage_k[slot];
-            const uint32_t dst = gdelta[(k >> shift) & dmask] + slot;
-            keys_out[dst] = k;
-            vals_out[dst] = stage_v[slot];
+            for (int w = 0; w < SORT_WAVES; ++w) { c[w] = cnt[w][d]; bc += c[w]; }
+            uint32_t tot;
+            const uint32_t loff = block_excl_scan(bc, tmp, &tot);                 // where digit d starts in the LDS stage
+            const uint32_t digit_excl = block_excl_scan(totals[d], tmp, &tot);    // where digit d starts globally
+            gdelta[d] = digit_excl + hist[(uint64_t)d * num_blocks + part] - loff;
+            uint32_t run = loff;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) { cnt[w][d] = run; run += c[w]; }
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            if (idx < n) {
+                const uint32_t pos = cnt[wave][(key[r] >> shift) & dmask] + rank[r];
+                stage_k[pos] = key[r];
+                stage_v[pos] = val[r];
+            }
+        }
+        __syncthreads();
+        const uint32_t nvalid = (uint32_t)((n - pbase) < (uint64_t)SORT_PART ? (n - pbase) : (uint64_t)SORT_PART);
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const uint32_t slot = (uint32_t)i * SORT_BLOCK + threadIdx.x;
+            if (slot < nvalid) {
+                const uint32_t k = stage_k[slot];
+                const uint32_t dst = gdelta[(k >> shift) & dmask] + slot;
+                keys_out[dst] = k;
+                vals_out[dst] = stage_v[slot];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -194,56 +206,61 @@ size_t dvs_sort_scratch_words(uint64_t n) {
 }
 
 hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch) {
+                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch, const uint64_t* n_dev,
+                                uint64_t n_expected) {
     if (n == 0) return hipSuccess;
-    const int items = sort_items_for(n);
+    const uint64_t n_grid = (n_dev && n_expected > 0 && n_expected < n) ? n_expected : n;      // the kernels stride over the partitions
+    const int items = sort_items_for(n_grid);
     const uint32_t nb = (uint32_t)((n + (uint64_t)SORT_BLOCK * items - 1) / ((uint64_t)SORT_BLOCK * items));
+    uint32_t ng = (uint32_t)((n_grid + (uint64_t)SORT_BLOCK * items - 1) / ((uint64_t)SORT_BLOCK * items));
+    if (ng > nb) ng = nb;
     uint32_t* hist = scratch;
     uint32_t* totals = scratch + (size_t)nb * RADIX;
     const uint32_t dmask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
-    if (items == 8) hipLaunchKernelGGL(k_sort_hist<8>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, dmask, hist, nb);
-    else hipLaunchKernelGGL(k_sort_hist<16>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, n, shift, dmask, hist, nb);
+    if (items == 8) hipLaunchKernelGGL(k_sort_hist<8>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, n, n_dev, shift, dmask, hist, nb);
+    else hipLaunchKernelGGL(k_sort_hist<16>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, n, n_dev, shift, dmask, hist, nb);
     hipLaunchKernelGGL(k_sort_rowscan, dim3(RADIX), dim3(SORT_BLOCK), 0, st, hist, nb, totals);
     if (items == 8)
-        hipLaunchKernelGGL(k_sort_scatter<8>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+        hipLaunchKernelGGL(k_sort_scatter<8>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, n_dev, shift,
                            dmask, hist, totals, nb);
     else
-        hipLaunchKernelGGL(k_sort_scatter<16>, dim3(nb), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+        hipLaunchKernelGGL(k_sort_scatter<16>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, n_dev, shift,
                            dmask, hist, totals, nb);
     return hipGetLastError();
 }
 
-// ---- tile rect of a visible splat: identical expressions to k_preprocess_fwd -----------------------
-__device__ __forceinline__ void splat_rect(float2 m, int radius, int tiles_x, int tiles_y, int& minx, int& miny, int& maxx,
-                                           int& maxy) {
-    const float radf = (float)radius;
-    const float gx = (float)tiles_x, gy = (float)tiles_y, inv_tile = 1.0f / DVS_TILE;
-    minx = (int)fminf(gx, fmaxf(0.f, (m.x - radf) * inv_tile));
-    miny = (int)fminf(gy, fmaxf(0.f, (m.y - radf) * inv_tile));
-    maxx = (int)fminf(gx, fmaxf(0.f, (m.x + radf + (float)(DVS_TILE - 1)) * inv_tile));
-    maxy = (int)fminf(gy, fmaxf(0.f, (m.y + radf + (float)(DVS_TILE - 1)) * inv_tile));
-}
-
 // ---- A3: scan of tiles_touched in depth-sorted order ------------------------------------------------
+// k_preprocess_fwd leaves each splat's tile rectangle as four u16 (8 B; an empty rectangle for culled splats). This kernel does the ONE
+// random gather of the binning stage — rect[sorted_ids[j]] — and re-emits the rectangles in depth order, so that the scan and the
+// duplication stream (round 1 gathered tiles_touched twice and the 64-B projected record once: 3.7x / 4.5x the algorithmic bytes).
+__device__ __forceinline__ uint32_t rect_tiles(uint2 r) {
+    return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));
+}
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ tiles_touched,
+k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted,
                 uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t tmp[SORT_WAVES + 1];
     const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
-    const uint32_t v = j < n ? tiles_touched[sorted_ids[j]] : 0u;
+    uint32_t v = 0;
+    if (j < n) {
+        const uint2 r = rect[sorted_ids[j]];
+        rect_sorted[j] = r;
+        v = rect_tiles(r);
+    }
     uint32_t tot;
     (void)block_excl_scan(v, tmp, &tot);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint64_t* __restrict__ total) {
+k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint64_t* __restrict__ total /*[0] = T, [1] += (T > capacity)*/,
+                   uint64_t capacity) {
     // one workgroup, one round: thread t owns a contiguous chunk of the block sums (a 256-at-a-time loop costs ~0.6 us per round:
     // 16 rounds at 1M splats), sums it, the 256 chunk sums are scanned once, then the chunk is rewritten as exclusive offsets
     __shared__ uint32_t tmp[SORT_WAVES + 1];
     const uint32_t per = (num_blocks + SORT_BLOCK - 1) / SORT_BLOCK;
     const uint32_t lo = threadIdx.x * per, hi = min(num_blocks, lo + per);
-    __shared__ unsigned long long wide;                  // the true 64-bit total: the caller rejects T >= 2^32 (offsets are 32-bit)
+    __shared__ unsigned long long wide;                  // the true 64-bit total: T >= 2^32 or > capacity is an error (offsets are 32-bit)
     if (threadIdx.x == 0) wide = 0ull;
     uint32_t s = 0;
     unsigned long long s64 = 0ull;
@@ -255,44 +272,44 @@ k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint6
     if ((threadIdx.x & 63) == 0) atomicAdd(&wide, s64);
     for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = block_sums[i]; block_sums[i] = run; run += v; }
     __syncthreads();
-    if (threadIdx.x == 0) *total = wide;
+    if (threadIdx.x == 0) { total[0] = wide; if (wide > capacity) total[1] += 1ull; }
 }
 
 size_t dvs_scan_scratch_words(int n) { return (size_t)((n + SORT_BLOCK - 1) / SORT_BLOCK) + 1; }
 
-hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
-                                uint32_t* block_offsets, uint64_t* total_dev) {
+hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect, uint32_t* rect_sorted,
+                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
-    if (nb > 0) hipLaunchKernelGGL(k_tile_blocksum, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, tiles_touched, block_offsets);
-    hipLaunchKernelGGL(k_tile_scan_blocks, dim3(1), dim3(SORT_BLOCK), 0, st, block_offsets, nb, total_dev);
+    if (nb > 0) hipLaunchKernelGGL(k_tile_blocksum, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect, (uint2*)rect_sorted, block_offsets);
+    hipLaunchKernelGGL(k_tile_scan_blocks, dim3(1), dim3(SORT_BLOCK), 0, st, block_offsets, nb, total_dev, capacity);
     return hipGetLastError();
 }
 
 // ---- A4: duplicate with keys, in depth-sorted order ---------------------------------------------------
+// Streams (splat id, rectangle) in depth order; instances beyond `capacity` are not written (k_tile_scan_blocks has raised the
+// overflow counter; the host reports DVS_ERR_CAPACITY — never a silent truncation).
 #define DUP_COOP_THRESHOLD 16
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ tiles_touched,
-            const uint32_t* __restrict__ block_offsets, const float4* __restrict__ splat2d,
-            int tiles_x, int tiles_y, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat) {
+k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rect_sorted,
+            const uint32_t* __restrict__ block_offsets, int tiles_x, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat,
+            uint64_t capacity) {
     __shared__ uint32_t tmp[SORT_WAVES + 1];
     const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
     uint32_t id = 0, touched = 0;
-    if (j < n) { id = sorted_ids[j]; touched = tiles_touched[id]; }
+    uint2 r = make_uint2(0u, 0u);
+    if (j < n) { id = sorted_ids[j]; r = rect_sorted[j]; touched = rect_tiles(r); }
     uint32_t tot;
     uint32_t off = block_excl_scan(touched, tmp, &tot) + block_offsets[blockIdx.x];
-    int minx = 0, miny = 0, maxx = 0, maxy = 0;
-    if (touched > 0) {          // mean and radius come from the splat's 64-B record (one line per gather)
-        const float4 r0 = splat2d[4 * (size_t)id];
-        const int radius = __float_as_int(splat2d[4 * (size_t)id + 2].z);
-        splat_rect(make_float2(r0.x, r0.y), radius, tiles_x, tiles_y, minx, miny, maxx, maxy);
-    }
+    const int minx = (int)(r.x & 0xFFFFu), miny = (int)(r.y & 0xFFFFu), maxx = (int)(r.x >> 16), maxy = (int)(r.y >> 16);
     const int w = maxx - minx;
     // small rects: the owning lane emits its tiles (row-major inside the rect)
     if (touched > 0 && touched <= DUP_COOP_THRESHOLD) {
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
-                inst_tile[off] = (uint32_t)(y * tiles_x + x);
-                inst_splat[off] = id;
+                if (off < capacity) {
+                    inst_tile[off] = (uint32_t)(y * tiles_x + x);
+                    inst_splat[off] = id;
+                }
                 ++off;
             }
     }
@@ -306,38 +323,42 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __re
         const int b_minx = __shfl(minx, src, 64), b_miny = __shfl(miny, src, 64), b_w = __shfl(w, src, 64);
         for (uint32_t k = lane; k < b_touched; k += 64) {
             const int y = b_miny + (int)(k / (uint32_t)b_w), x = b_minx + (int)(k % (uint32_t)b_w);
-            inst_tile[b_off + k] = (uint32_t)(y * tiles_x + x);
-            inst_splat[b_off + k] = b_id;
+            if ((uint64_t)b_off + k < capacity) {
+                inst_tile[b_off + k] = (uint32_t)(y * tiles_x + x);
+                inst_splat[b_off + k] = b_id;
+            }
         }
     }
 }
 
-hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
-                                const uint32_t* block_offsets, const float* splat2d, int tiles_x,
-                                int tiles_y, uint32_t* inst_tile, uint32_t* inst_splat) {
+hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
+                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, tiles_touched, block_offsets,
-                       (const float4*)splat2d, tiles_x, tiles_y, inst_tile, inst_splat);
+    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect_sorted, block_offsets,
+                       tiles_x, inst_tile, inst_splat, capacity);
     return hipGetLastError();
 }
 
 // ---- A6: tile ranges -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_tile_ranges(uint64_t T, const uint32_t* __restrict__ sorted_tile, uint2* __restrict__ ranges) {
-    const uint64_t j = (uint64_t)blockIdx.x * SORT_BLOCK + threadIdx.x;
-    if (j >= T) return;
-    const uint32_t t = sorted_tile[j];
-    if (j == 0 || sorted_tile[j - 1] != t) ranges[t].x = (uint32_t)j;
-    if (j + 1 == T || sorted_tile[j + 1] != t) ranges[t].y = (uint32_t)(j + 1);
+k_tile_ranges(uint64_t T_host, const uint64_t* __restrict__ T_dev, const uint32_t* __restrict__ sorted_tile, uint2* __restrict__ ranges) {
+    const uint64_t T = T_dev ? (*T_dev < T_host ? *T_dev : T_host) : T_host;
+    for (uint64_t j = (uint64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; j < T; j += (uint64_t)gridDim.x * SORT_BLOCK) {
+        const uint32_t t = sorted_tile[j];
+        if (j == 0 || sorted_tile[j - 1] != t) ranges[t].x = (uint32_t)j;
+        if (j + 1 == T || sorted_tile[j + 1] != t) ranges[t].y = (uint32_t)(j + 1);
+    }
 }
 
-hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles) {
+hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles, const uint64_t* T_dev,
+                                  uint64_t T_expected) {
     hipError_t e = hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (T == 0) return hipSuccess;
-    const uint32_t nb = (uint32_t)((T + SORT_BLOCK - 1) / SORT_BLOCK);
-    hipLaunchKernelGGL(k_tile_ranges, dim3(nb), dim3(SORT_BLOCK), 0, st, T, sorted_tile, (uint2*)ranges);
+    const uint64_t T_grid = (T_dev && T_expected > 0 && T_expected < T) ? T_expected : T;
+    const uint32_t nb = (uint32_t)((T_grid + SORT_BLOCK - 1) / SORT_BLOCK);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(nb), dim3(SORT_BLOCK), 0, st, T, T_dev, sorted_tile, (uint2*)ranges);
     return hipGetLastError();
 }
 

@@ -66,13 +66,16 @@ struct dvs_ctx {
     int device = 0;
     size_t max_splats = 0;
     int max_w = 0, max_h = 0;
-    Buf radii, splat2d, depth, flags, tiles_touched, key[2], ids[2], scan_blocks;
+    Buf radii, splat2d, depth, flags, tiles_touched, rect, rect_sorted, key[2], ids[2], scan_blocks;
     Buf inst_tile[2], inst_splat[2];
     Buf sort_scratch, tmp_keys, tmp_vals;
     Buf ranges, final_T, n_contrib;
     Buf g_rows;
-    uint64_t* total_dev = nullptr;
-    uint64_t* total_host = nullptr;      // pinned
+    uint64_t* total_dev = nullptr;       // [0] = T of the last forward, [1] = number of forwards whose T exceeded the instance capacity
+    uint64_t* total_host = nullptr;      // pinned copy of both words (async: refreshed by every forward, read by the next one)
+    uint64_t inst_cap = 0;               // instances the instance arenas can hold
+    bool async_T = false;                // dvs_set_async: no host synchronisation inside dvs_raster_forward
+    uint64_t overflow_seen = 0;          // value of total_host[1] already reported
     dvs_fwd_state st{};
     bool have_fwd = false;
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
@@ -130,7 +133,7 @@ int ensure_splat_arenas(dvs_ctx* c, size_t n) {
     int r;
 #define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
     ENS(radii, n * 4) ENS(splat2d, n * 64) ENS(depth, n * 4)
-    ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
+    ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(rect, n * 8) ENS(rect_sorted, n * 8) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
     ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
     ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)
     ENS(g_rows, n * 48)
@@ -153,6 +156,13 @@ int ensure_instance_arenas(dvs_ctx* c, uint64_t T) {
         if ((r = c->inst_splat[k].ensure(T * 4)) != DVS_OK) return r;
     }
     if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(T) * 4)) != DVS_OK) return r;
+    c->inst_cap = c->inst_tile[0].bytes / 4;
+    for (int k = 0; k < 2; ++k) {
+        if (c->inst_tile[k].bytes / 4 < c->inst_cap) c->inst_cap = c->inst_tile[k].bytes / 4;
+        if (c->inst_splat[k].bytes / 4 < c->inst_cap) c->inst_cap = c->inst_splat[k].bytes / 4;
+    }
+    if (c->inst_cap >= (1ull << 32)) c->inst_cap = (1ull << 32) - 1;       // instance offsets are 32-bit
+    if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(c->inst_cap) * 4)) != DVS_OK) return r;      // async: grids are sized for the capacity
     return DVS_OK;
 }
 }  // namespace
@@ -174,11 +184,14 @@ dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
     c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h;
     if (const char* v = getenv("DVS_BWD_VARIANT")) c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_REDUCE;
     if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
-    if (hipMalloc((void**)&c->total_dev, 8) != hipSuccess || hipHostMalloc((void**)&c->total_host, 8, hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc((void**)&c->total_dev, 16) != hipSuccess || hipHostMalloc((void**)&c->total_host, 16, hipHostMallocDefault) != hipSuccess ||
+        hipMemset(c->total_dev, 0, 16) != hipSuccess) {
         g_last_error = "dvs_create: hipMalloc failed";
         delete c;
         return nullptr;
     }
+    c->total_host[0] = c->total_host[1] = 0;
+    if (const char* v = getenv("DVS_ASYNC")) c->async_T = v[0] == '1';
     if (ensure_splat_arenas(c, max_splats) != DVS_OK || ensure_image_arenas(c, max_w, max_h) != DVS_OK ||
         ensure_instance_arenas(c, (uint64_t)max_splats * 4) != DVS_OK) {
         dvs_destroy(c);
@@ -190,7 +203,7 @@ dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
 void dvs_destroy(dvs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    Buf* all[] = {&c->radii, &c->splat2d, &c->depth, &c->flags, &c->tiles_touched, &c->key[0], &c->key[1],
+    Buf* all[] = {&c->radii, &c->splat2d, &c->depth, &c->flags, &c->tiles_touched, &c->rect, &c->rect_sorted, &c->key[0], &c->key[1],
                   &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
                   &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows};
     for (Buf* b : all) b->release();
@@ -227,7 +240,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
                                        opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
                                        c->depth.as<float>(),
                                        c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
-                                       c->ids[0].as<uint32_t>(), opts->shn_layout));
+                                       c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>()));
     size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
     // A5 (low 32 key bits): depth sort over splats, 4 x 8-bit LSD passes
     int cur = 0;
@@ -237,21 +250,47 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
         cur ^= 1;
     }
     size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
-    // A3 scan in depth order
-    HIPCHECK(dvs_launch_tile_scan(st, n, c->ids[cur].as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
-                                  c->total_dev));
-    HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 8, hipMemcpyDeviceToHost, st));
+    // A3 scan in depth order (the one random gather of the binning stage: the tile rectangles)
+    uint64_t T = 0, T_expected = 0;
+    const uint64_t* T_dev = nullptr;           // async: the kernels over instances read T on the device, grids sized for the capacity
+    if (c->async_T) {
+        // No host synchronisation: the arenas are over-allocated, T stays on the device. What the host knows is the T of EARLIER
+        // forwards on this context (pinned copy, refreshed asynchronously): it grows the arenas ahead of need and reports an overflow
+        // (T beyond the capacity: that view's outputs are invalid, nothing was written out of bounds) as DVS_ERR_CAPACITY, once.
+        const uint64_t lastT = c->total_host[0], overflow = c->total_host[1];
+        if (overflow != c->overflow_seen) {
+            c->overflow_seen = overflow;
+            HIPCHECK(hipStreamSynchronize(st));
+            int r = ensure_instance_arenas(c, lastT + lastT / 2);
+            if (r != DVS_OK) return r;
+            g_last_error = "dvs_raster_forward (async): an earlier forward on this context produced more tile instances than the instance "
+                           "arena held; its outputs are invalid. The arena has been enlarged — repeat that view.";
+            return DVS_ERR_CAPACITY;
+        }
+        if (lastT + lastT / 8 > c->inst_cap) {            // getting close: grow before it can overflow (rare; needs the stream idle)
+            HIPCHECK(hipStreamSynchronize(st));
+            int r = ensure_instance_arenas(c, lastT + lastT / 2);
+            if (r != DVS_OK) return r;
+        }
+        T = c->inst_cap;
+        T_dev = c->total_dev;
+        T_expected = lastT > 0 ? lastT + lastT / 16 + 4096 : 0;      // grid size only: the kernels stride over whatever T turns out to be
+    }
+    HIPCHECK(dvs_launch_tile_scan(st, n, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
+                                  c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull));
+    HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 16, hipMemcpyDeviceToHost, st));
     size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
-    HIPCHECK(hipStreamSynchronize(st));
-    const uint64_t T = *c->total_host;
-    if (T >= (1ull << 32)) { g_last_error = "dvs_raster_forward: more than 2^32 tile instances"; return DVS_ERR_CAPACITY; }
-    { int r = ensure_instance_arenas(c, T ? T : 1); if (r != DVS_OK) return r; }
+    if (!c->async_T) {
+        HIPCHECK(hipStreamSynchronize(st));
+        T = c->total_host[0];
+        if (T >= (1ull << 32)) { g_last_error = "dvs_raster_forward: more than 2^32 tile instances"; return DVS_ERR_CAPACITY; }
+        { int r = ensure_instance_arenas(c, T ? T : 1); if (r != DVS_OK) return r; }
+    }
 
     // A4 duplicate
     size_t e4 = tm.mark();
-    HIPCHECK(dvs_launch_duplicate(st, n, c->ids[cur].as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
-                                  c->splat2d.as<float>(), tiles_x, tiles_y, c->inst_tile[0].as<uint32_t>(),
-                                  c->inst_splat[0].as<uint32_t>()));
+    HIPCHECK(dvs_launch_duplicate(st, n, c->ids[cur].as<uint32_t>(), c->rect_sorted.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
+                                  tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap));
     size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
     // A5 (high key bits): tile-id sort over instances
     int icur = 0;
@@ -259,12 +298,12 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     for (int shift = 0; shift < tile_bits; shift += 8) {
         HIPCHECK(dvs_launch_sort_pass(st, c->inst_tile[icur].as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                       c->inst_tile[icur ^ 1].as<uint32_t>(), c->inst_splat[icur ^ 1].as<uint32_t>(), T, shift,
-                                      tile_bits - shift, c->sort_scratch.as<uint32_t>()));
+                                      tile_bits - shift, c->sort_scratch.as<uint32_t>(), T_dev, T_expected));
         icur ^= 1;
     }
     size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
     // A6 ranges
-    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles));
+    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles, T_dev, T_expected));
     size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     // A7 composite
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
@@ -285,10 +324,10 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     s.tiles_touched = c->tiles_touched.as<uint32_t>();
     s.sorted_tile = c->inst_tile[icur].as<uint32_t>(); s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
     s.ranges = c->ranges.as<uint32_t>(); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
-    s.num_rendered = T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y; s._pad = 0;
+    s.num_rendered = c->async_T ? DVS_T_UNKNOWN : T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y; s._pad = 0;
     c->have_fwd = true;
     if (saved) *saved = s;
-    if (num_rendered) *num_rendered = T;
+    if (num_rendered) *num_rendered = c->async_T ? DVS_T_UNKNOWN : T;
     if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, false); }
     return DVS_OK;
 }
@@ -408,6 +447,7 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
 int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
     if (!c || !out_keys) { g_last_error = "dvs_export_sorted_keys: null argument"; return DVS_ERR_INVALID; }
     if (!c->have_fwd) { g_last_error = "dvs_export_sorted_keys: no forward state"; return DVS_ERR_STATE; }
+    if (c->st.num_rendered == DVS_T_UNKNOWN) { uint64_t t; int r = dvs_get_num_rendered(c, stream, &t); if (r != DVS_OK) return r; }
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(dvs_launch_export_keys((hipStream_t)stream, c->st.num_rendered, c->st.sorted_tile, c->st.sorted_splat, c->st.depth, out_keys));
     return DVS_OK;
@@ -427,6 +467,28 @@ int dvs_sh_grad_combine(dvs_ctx* c, void* stream, int n, const float* pos, int s
     }
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(dvs_launch_sh_grad_combine((hipStream_t)stream, n, pos, sh_degree, n_views, campos, dcolor, g_sh0, g_shN, accumulate, shn_layout));
+    return DVS_OK;
+}
+
+int dvs_set_async(dvs_ctx* c, int enable) {
+    if (!c) { g_last_error = "dvs_set_async: null context"; return DVS_ERR_INVALID; }
+    c->async_T = enable != 0;
+    return DVS_OK;
+}
+int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
+    if (!c || !T) { g_last_error = "dvs_get_num_rendered: null argument"; return DVS_ERR_INVALID; }
+    if (!c->have_fwd) { g_last_error = "dvs_get_num_rendered: no forward state"; return DVS_ERR_STATE; }
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    *T = c->total_host[0];
+    c->st.num_rendered = *T;
+    if (c->total_host[1] != c->overflow_seen) {
+        c->overflow_seen = c->total_host[1];
+        (void)ensure_instance_arenas(c, *T + *T / 2);
+        g_last_error = "dvs_get_num_rendered: the last forward produced more tile instances than the instance arena held; its outputs are "
+                       "invalid. The arena has been enlarged — repeat that view.";
+        return DVS_ERR_CAPACITY;
+    }
     return DVS_OK;
 }
 

@@ -9,7 +9,7 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
                                      float* depth, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled);
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect /*[n,2]: 4 x u16*/);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
@@ -26,18 +26,21 @@ hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, floa
 // Number of uint32 scratch words dvs_launch_sort_pass needs for n items.
 size_t dvs_sort_scratch_words(uint64_t n);
 // One stable LSD pass (digit = `bits` (<= 8) key bits at `shift`) of (key,val) pairs: in -> out.
+// n_dev (nullable): the item count lives on the device (min(*n_dev, n) items are sorted; n sizes the grid) — no host round trip for T.
 hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch);
-// A3: offsets over tiles_touched in depth-sorted order. Writes block offsets and the total (device + pinned host).
+                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch, const uint64_t* n_dev = nullptr,
+                                uint64_t n_expected = 0 /*with n_dev: sizes the grid (the kernels stride over the partitions of n)*/);
+// A3: gathers the tile rectangles (4 x u16 per splat, written by A2) into depth order, offsets over their areas. Writes block offsets
+// and total_dev[0] = T; total_dev[1] is incremented when T exceeds `capacity` (instances the arenas can hold).
 size_t dvs_scan_scratch_words(int n);
-hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
-                                uint32_t* block_offsets, uint64_t* total_dev);
-// A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order.
-hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* tiles_touched,
-                                const uint32_t* block_offsets, const float* splat2d, int tiles_x,
-                                int tiles_y, uint32_t* inst_tile, uint32_t* inst_splat);
-// A6: per-tile [start,end) from the sorted tile ids.
-hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles);
+hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect, uint32_t* rect_sorted,
+                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity);
+// A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order (streams ids + sorted rectangles).
+hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
+                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity);
+// A6: per-tile [start,end) from the sorted tile ids. T_dev (nullable): device-side count, T sizes the grid.
+hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles,
+                                  const uint64_t* T_dev = nullptr, uint64_t T_expected = 0);
 // canonical 64-bit keys of the sorted list (parity export)
 hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, const uint32_t* sorted_splat,
                                   const float* depth, uint64_t* out_keys);

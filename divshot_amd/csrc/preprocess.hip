@@ -73,7 +73,8 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
                  DvsCam cam, int deg, int antialias, int tiles_x, int tiles_y,
                  int* __restrict__ radii, float4* __restrict__ splat2d /*[n] 64-B records, DVS_S2D_* */, float* __restrict__ depth,
                  uint32_t* __restrict__ flags,
-                 uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids) {
+                 uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
+                 uint2* __restrict__ rect /*tile rectangle [minx | maxx << 16, miny | maxy << 16]; empty for culled splats*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] when deg>0
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
@@ -99,6 +100,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
 
     int out_radius = 0;
     uint32_t out_tiles = 0, out_flags = 0, out_key = 0xFFFFFFFFu;
+    uint2 out_rect = make_uint2(0u, 0u);
     float2 out_mean = make_float2(0.f, 0.f);
     float out_depth = 0.f;
     float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -220,6 +222,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         out_co = make_float4(c * det_inv, -b * det_inv, a * det_inv, opac);
         out_flags = fl;
         out_tiles = (uint32_t)touched;
+        out_rect = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
     } while (0);
 
     radii[i] = out_radius;
@@ -246,6 +249,7 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
     }
     flags[i] = out_flags;
     tiles_touched[i] = out_tiles;
+    rect[i] = out_rect;
     depth_key[i] = out_key;
     ids[i] = (uint32_t)i;
 }
@@ -694,18 +698,18 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
                                      float* depth, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled) {
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     if (shn_tiled) {
         hipLaunchKernelGGL(k_preprocess_fwd<true>, dim3(grid), dim3(PP_BLOCK), 0, st, n, pos, sh0, shN, opacity, scale, rot, cam,
                            deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,
-                           tiles_touched, depth_key, ids);
+                           tiles_touched, depth_key, ids, (uint2*)rect);
     } else {
         const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;
         hipLaunchKernelGGL(k_preprocess_fwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, sh0, shN, opacity, scale, rot, cam,
                            deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,
-                           tiles_touched, depth_key, ids);
+                           tiles_touched, depth_key, ids, (uint2*)rect);
     }
     return hipGetLastError();
 }

@@ -82,6 +82,20 @@ class Rasterizer:
     def keep_intermediates(self, on=True):
         check(lib.dvs_keep_bwd_intermediates(self.ctx, 1 if on else 0))
 
+    def set_async(self, on=True):
+        """dvs_set_async: forward never synchronises the stream; T stays on the device (num_rendered unknown until get_num_rendered())."""
+        check(lib.dvs_set_async(self.ctx, 1 if on else 0), "dvs_set_async")
+
+    def get_num_rendered(self):
+        """Synchronises the current stream and returns T of the last forward (raises DvsError on an instance-arena overflow)."""
+        T = C.c_uint64(0)
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_get_num_rendered(self.ctx, _stream_ptr(), C.byref(T)), "dvs_get_num_rendered")
+        self.num_rendered = int(T.value)
+        if self.state is not None:
+            self.state.num_rendered = self.num_rendered
+        return self.num_rendered
+
     def set_backward_variant(self, variant):
         """A8 kernel: 1 / "reduce" (default), 0 / "blocks", 2 / "mm" (experiments) — see dvs_raster.h."""
         v = {"blocks": 0, "reduce": 1, "mm": 2}.get(variant, variant)
@@ -204,6 +218,8 @@ class Rasterizer:
     def saved(self):
         """Host copies of every saved forward array (dict of numpy arrays)."""
         s = self.state
+        if s.num_rendered == 2 ** 64 - 1:          # DVS_T_UNKNOWN (asynchronous forward): ask for it
+            self.get_num_rendered()
         n, T, W, H = s.n, s.num_rendered, s.width, s.height
         tiles = s.tiles_x * s.tiles_y
         rec = self._d2h(s.splat2d, (n, 16), np.float32)          # the packed 64-B record (DVS_S2D_* offsets)
@@ -218,6 +234,8 @@ class Rasterizer:
         }
 
     def sorted_keys(self):
+        if self.state.num_rendered == 2 ** 64 - 1:
+            self.get_num_rendered()
         T = self.state.num_rendered
         buf = torch.empty((max(T, 1),), dtype=torch.int64, device=self.tdev)
         check(lib.dvs_export_sorted_keys(self.ctx, _stream_ptr(), buf.data_ptr()), "dvs_export_sorted_keys")

@@ -159,7 +159,7 @@ void     dvs_destroy(dvs_ctx* ctx);
 /* Forward: A2 preprocess -> A3 scan -> A4 duplicate -> A5 radix sort -> A6 ranges -> A7 composite.
  *   out_rgb: DEVICE [3,H,W] planar fp32.  saved: filled with pointers into ctx arenas (may be NULL).
  *   num_rendered: host pointer, may be NULL.
- * Synchronises `stream` once internally (reads the instance count T to size the sort). */
+ * Synchronises `stream` once internally (reads the instance count T to size the sort) unless dvs_set_async(ctx, 1). */
 int dvs_raster_forward(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                        const dvs_opts* opts, float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered);
 
@@ -188,6 +188,17 @@ int dvs_sh_grad_combine(dvs_ctx* ctx, void* stream, int n, const float* pos, int
                         const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_layout);
 /* Convert an shN array (DEVICE, src != dst) between DVS_SHN_ROWS [n*45] and DVS_SHN_TILED [ceil(n/64)*64*48]. */
 int dvs_shn_relayout(dvs_ctx* ctx, void* stream, int n, const float* src, float* dst, int to_tiled);
+
+/* Asynchronous forward. By default dvs_raster_forward synchronises `stream` once (it reads the instance count T to size the sort).
+ * With dvs_set_async(ctx, 1) it never synchronises: the instance arena is over-allocated, T stays on the device and every kernel over
+ * instances reads it there; *num_rendered and saved->num_rendered are DVS_T_UNKNOWN (dvs_get_num_rendered synchronises on demand).
+ * The host learns the T of EARLIER forwards on the context from an asynchronously refreshed pinned copy and enlarges the arena ahead of
+ * need. If a forward nevertheless produces more instances than the arena holds, nothing is written out of bounds, that view's outputs
+ * are invalid, and the next dvs_raster_forward / dvs_get_num_rendered on the context returns DVS_ERR_CAPACITY once (after enlarging
+ * the arena) — a hard error, never a silent truncation (SURVEY.md §7 "tile-list overflow"). DVS_ASYNC=1 sets the default. */
+#define DVS_T_UNKNOWN (~0ull)
+int dvs_set_async(dvs_ctx* ctx, int enable);
+int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
 
 /* The composite kernels exist in several variants with the same inputs and outputs, kept selectable so that the measured
  * comparison can be repeated (all of them pass the same parity tests). Backward (A8), results equal to fp32 roundoff:

@@ -547,3 +547,61 @@ def test_error_paths_and_nan_inputs(gpu_device):
     torch.cuda.synchronize()
     assert all(torch.isfinite(v).all() for v in grads.values())
     r.close()
+
+
+def test_async_forward_no_host_sync(gpu_device):
+    """dvs_set_async: T stays on the device (SURVEY.md §8(a) A3 "avoid the readback"): same image, same saved state and same
+    gradients as the synchronous forward; an instance-arena overflow is a hard error reported by the next call, after which the
+    enlarged arena renders the view correctly."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H = 30_000, 400, 300
+    spec = dv.make_spec(n, W, H, sh_degree=2, seed=3)
+    P = dv.synth_splats(spec); cam = dv.synth_camera(spec, 0); tgt = torch.from_numpy(dv.synth_target(spec, 0)).cuda()
+    r = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    Pd = params_to_device(P, r.tdev)
+    img_s = r.forward(Pd, cam, sh_degree=2, absgrad=True).clone()
+    T_sync = r.num_rendered
+    saved_s = r.saved()
+    g_s = {k: v.clone() for k, v in r.backward(((img_s - tgt) / (W * H)).contiguous()).items()}
+    r.set_async(True)
+    img_a = r.forward(Pd, cam, sh_degree=2, absgrad=True)
+    assert r.num_rendered == 2 ** 64 - 1                       # DVS_T_UNKNOWN until asked for
+    g_a = r.backward(((img_a - tgt) / (W * H)).contiguous())
+    assert r.get_num_rendered() == T_sync
+    saved_a = r.saved()
+    assert torch.equal(img_s, img_a)
+    for k in ("radii", "vals", "sorted_tile", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(saved_s[k], saved_a[k], err_msg=k)
+    for k in KEYS:
+        m, worst = rel_close(g_a[k].cpu().numpy(), g_s[k].cpu().numpy(), 1e-4, 2e-6)       # fp32 atomics: not bit-reproducible
+        assert m.all(), (k, worst)
+    r.close()
+    # overflow: splats covering ~30 tiles each against an arena sized for 5 per splat
+    spec = dv.make_spec(8000, 640, 480, sh_degree=0, seed=4, scale_log_offset=2.2)
+    P = dv.synth_splats(spec); cam = dv.synth_camera(spec, 0)
+    big = Rasterizer(0, max_splats=8000, max_w=640, max_h=480)
+    Pd = params_to_device(P, big.tdev)
+    ref = big.forward(Pd, cam, sh_degree=0).clone()
+    T_true = big.num_rendered
+    assert T_true > 6 * 8000, T_true
+    big.close()
+    small = Rasterizer(0, max_splats=8000, max_w=640, max_h=480)
+    small.set_async(True)
+    small.forward(Pd, cam, sh_degree=0)                         # overflows the fresh arena (nothing is written out of bounds)
+    with pytest.raises(dv.DvsError, match="more tile instances"):
+        small.get_num_rendered()
+    img = small.forward(Pd, cam, sh_degree=0)                   # the arena was enlarged by the failed call
+    assert small.get_num_rendered() == T_true
+    assert torch.equal(img, ref)
+    # the same overflow noticed by the next forward instead of by the getter
+    small2 = Rasterizer(0, max_splats=8000, max_w=640, max_h=480)
+    small2.set_async(True)
+    small2.forward(Pd, cam, sh_degree=0)
+    torch.cuda.synchronize()
+    with pytest.raises(dv.DvsError, match="more tile instances"):
+        small2.forward(Pd, cam, sh_degree=0)
+    img = small2.forward(Pd, cam, sh_degree=0)
+    torch.cuda.synchronize()
+    assert torch.equal(img, ref)
+    small.close(); small2.close()
