@@ -95,6 +95,15 @@ _PROTOS = {
     "dvs_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dvs_device_malloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "dvs_device_free": (None, [C.c_void_p, C.c_void_p]),
+    "dvs_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "dvs_comm_destroy": (None, [C.c_void_p]),
+    "dvs_comm_rank": (C.c_int, [C.c_void_p]),
+    "dvs_comm_world": (C.c_int, [C.c_void_p]),
+    "dvs_comm_all_reduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dvs_comm_all_reduce_max_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dvs_comm_reduce_scatter_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dvs_comm_all_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dvs_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "dvs_last_error": (C.c_char_p, []),
     "dvs_version": (C.c_char_p, []),
     "dvs_synth_splats": (C.c_int, [C.POINTER(SceneSpec)] + [C.c_void_p] * 6),

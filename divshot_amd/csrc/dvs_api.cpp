@@ -27,6 +27,7 @@ static void set_error(const char* what, hipError_t e, const char* file, int line
     snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
     g_last_error = buf;
 }
+void dvs_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }      // shared with dvs_comm.cpp
 #define HIPCHECK(expr)                                                   \
     do {                                                                 \
         hipError_t _e = (expr);                                          \

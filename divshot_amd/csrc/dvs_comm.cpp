@@ -1,0 +1,181 @@
+// dvs_comm.cpp — include/dvs_comm.h: RCCL behind a plain-C surface (data-parallel exchange of the training step).
+// librccl is dlopen()ed on first use; the unique id travels from rank 0 to the other ranks over one TCP connection each.
+#include <hip/hip_runtime.h>
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include "../../include/dvs_comm.h"
+#include "../../include/dvs_raster.h"
+
+// the slice of rccl.h this file needs (types and enum values as /opt/rocm/include/rccl/rccl.h, RCCL 2.x ABI)
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { rcclSum = 0, rcclMax = 2 };
+enum { rcclUint8 = 1, rcclInt32 = 2, rcclFloat32 = 7 };
+}
+
+void dvs_set_last_error(const char* msg);      // dvs_api.cpp
+
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    bool load(std::string& err) {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+#define SYM(field, name) field = (decltype(field))dlsym(handle, name); if (!field) { err = "librccl lacks " name; return false; }
+        SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+        SYM(GetErrorString, "ncclGetErrorString") SYM(AllReduce, "ncclAllReduce") SYM(ReduceScatter, "ncclReduceScatter")
+        SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast")
+#undef SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+
+bool send_all(int fd, const void* p, size_t n) {
+    const char* c = (const char*)p;
+    while (n) { ssize_t k = ::send(fd, c, n, 0); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+bool recv_all(int fd, void* p, size_t n) {
+    char* c = (char*)p;
+    while (n) { ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+// rank 0 hands the 128-byte id to world-1 peers; a peer retries the connection for up to ~120 s (ranks start at different times)
+bool exchange_id(ncclUniqueId* id, int rank, int world, const char* addr, int port, std::string& err) {
+    if (world == 1) return true;
+    if (rank == 0) {
+        int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (ls < 0) { err = "socket() failed"; return false; }
+        int one = 1; setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
+        if (::bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || ::listen(ls, world) != 0) { err = "bind/listen on MASTER_PORT failed"; ::close(ls); return false; }
+        for (int k = 1; k < world; ++k) {
+            int fd = ::accept(ls, nullptr, nullptr);
+            if (fd < 0 || !send_all(fd, id, sizeof *id)) { err = "sending the RCCL id failed"; if (fd >= 0) ::close(fd); ::close(ls); return false; }
+            ::close(fd);
+        }
+        ::close(ls);
+        return true;
+    }
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+    char pbuf[16]; snprintf(pbuf, sizeof pbuf, "%d", port);
+    if (getaddrinfo(addr, pbuf, &hints, &res) != 0 || !res) { err = std::string("cannot resolve ") + addr; return false; }
+    bool ok = false;
+    for (int attempt = 0; attempt < 1200 && !ok; ++attempt) {
+        int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) ok = recv_all(fd, id, sizeof *id);
+        if (fd >= 0) ::close(fd);
+        if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    freeaddrinfo(res);
+    if (!ok) err = "no RCCL id from rank 0 (is it running and MASTER_ADDR / MASTER_PORT the same on every rank?)";
+    return ok;
+}
+}  // namespace
+
+struct dvs_comm {
+    int device = 0, rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+};
+
+#define RCCLCHECK(expr)                                                                                            \
+    do {                                                                                                           \
+        ncclResult_t r_ = (expr);                                                                                  \
+        if (r_ != 0) { std::string m_ = std::string(#expr ": ") + g_rccl.GetErrorString(r_); dvs_set_last_error(m_.c_str()); return DVS_ERR_HIP; } \
+    } while (0)
+
+extern "C" {
+
+dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_addr, int master_port) {
+    std::string err;
+    if (world < 1) {
+        const char* r = getenv("RANK"); const char* w = getenv("WORLD_SIZE");
+        rank = r ? atoi(r) : 0; world = w ? atoi(w) : 1;
+        if (!master_addr) master_addr = getenv("MASTER_ADDR");
+        if (master_port <= 0) { const char* p = getenv("MASTER_PORT"); master_port = p ? atoi(p) : 29500; }
+    }
+    if (!master_addr || !*master_addr) master_addr = "127.0.0.1";
+    if (master_port <= 0) master_port = 29500;
+    if (rank < 0 || rank >= world) { dvs_set_last_error("dvs_comm_create: rank outside [0, world)"); return nullptr; }
+    if (!g_rccl.load(err)) { dvs_set_last_error(("dvs_comm_create: " + err).c_str()); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { dvs_set_last_error("dvs_comm_create: hipSetDevice failed"); return nullptr; }
+    ncclUniqueId id;
+    memset(&id, 0, sizeof id);
+    if (rank == 0) {
+        ncclResult_t r = g_rccl.GetUniqueId(&id);
+        if (r != 0) { dvs_set_last_error((std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r)).c_str()); return nullptr; }
+    }
+    if (!exchange_id(&id, rank, world, master_addr, master_port, err)) { dvs_set_last_error(("dvs_comm_create: " + err).c_str()); return nullptr; }
+    dvs_comm* c = new dvs_comm();
+    c->device = device; c->rank = rank; c->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) { dvs_set_last_error((std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)).c_str()); delete c; return nullptr; }
+    return c;
+}
+
+void dvs_comm_destroy(dvs_comm* c) {
+    if (!c) return;
+    if (c->comm) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->comm); }
+    delete c;
+}
+int dvs_comm_rank(const dvs_comm* c) { return c ? c->rank : 0; }
+int dvs_comm_world(const dvs_comm* c) { return c ? c->world : 1; }
+
+int dvs_comm_all_reduce_sum_f32(dvs_comm* c, void* stream, float* buf, size_t count) {
+    if (!c || (count && !buf)) { dvs_set_last_error("dvs_comm_all_reduce_sum_f32: null argument"); return DVS_ERR_INVALID; }
+    if (!count) return DVS_OK;
+    RCCLCHECK(g_rccl.AllReduce(buf, buf, count, rcclFloat32, rcclSum, c->comm, (hipStream_t)stream));
+    return DVS_OK;
+}
+int dvs_comm_all_reduce_max_i32(dvs_comm* c, void* stream, int32_t* buf, size_t count) {
+    if (!c || (count && !buf)) { dvs_set_last_error("dvs_comm_all_reduce_max_i32: null argument"); return DVS_ERR_INVALID; }
+    if (!count) return DVS_OK;
+    RCCLCHECK(g_rccl.AllReduce(buf, buf, count, rcclInt32, rcclMax, c->comm, (hipStream_t)stream));
+    return DVS_OK;
+}
+int dvs_comm_reduce_scatter_sum_f32(dvs_comm* c, void* stream, const float* send, float* recv, size_t recv_count) {
+    if (!c || (recv_count && (!send || !recv))) { dvs_set_last_error("dvs_comm_reduce_scatter_sum_f32: null argument"); return DVS_ERR_INVALID; }
+    if (!recv_count) return DVS_OK;
+    RCCLCHECK(g_rccl.ReduceScatter(send, recv, recv_count, rcclFloat32, rcclSum, c->comm, (hipStream_t)stream));
+    return DVS_OK;
+}
+int dvs_comm_all_gather_f32(dvs_comm* c, void* stream, const float* send, float* recv, size_t send_count) {
+    if (!c || (send_count && (!send || !recv))) { dvs_set_last_error("dvs_comm_all_gather_f32: null argument"); return DVS_ERR_INVALID; }
+    if (!send_count) return DVS_OK;
+    RCCLCHECK(g_rccl.AllGather(send, recv, send_count, rcclFloat32, c->comm, (hipStream_t)stream));
+    return DVS_OK;
+}
+int dvs_comm_broadcast(dvs_comm* c, void* stream, void* buf, size_t bytes, int root) {
+    if (!c || (bytes && !buf) || root < 0 || root >= c->world) { dvs_set_last_error("dvs_comm_broadcast: bad argument"); return DVS_ERR_INVALID; }
+    if (!bytes) return DVS_OK;
+    RCCLCHECK(g_rccl.Broadcast(buf, buf, bytes, rcclUint8, root, c->comm, (hipStream_t)stream));
+    return DVS_OK;
+}
+
+}  // extern "C"

@@ -5,9 +5,15 @@
 // sequence and ownership rules (scene allocated/freed by the plugin, config copied, bool from load_train_data) and
 // puts the MI355X rasterizer (include/dvs_raster.h) at the centre of train_step():
 //     sample camera -> dvs_raster_forward -> (1-w) L1 + w (1-SSIM) loss gradient -> dvs_raster_backward -> fused Adam -> step++
-// -> every refineEvery steps clone / split / prune (ADC) and every resetAlphaEvery steps the opacity reset.
-// Out of scope this round: MCMC relocation, COLMAP / image ingestion,
-// mesh export. load_train_data accepts a synthetic-scene spec instead of a dataset path.
+// -> every refineEvery steps the densification strategy (0 ADC clone / split / prune, 1 MCMC relocation + growth, 2 ADC+), the
+// opacity reset every resetAlphaEvery steps, a light prune pass every pruneInterval steps after refinement has stopped.
+// With WORLD_SIZE > 1 (one process per GPU, launched with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) the step is
+// data parallel: every rank holds a replica, renders its own camera of the iteration, the gradient rows are summed
+// with ONE RCCL all-reduce over xGMI (include/dvs_comm.h), the densification statistics likewise before each refinement, and the
+// optimizer / densifier run replicated and deterministic so that the replicas stay bit-identical.
+// Out of scope: COLMAP / image ingestion, mesh export, the 2DGS model type. load_train_data accepts a
+// synthetic-scene spec instead of a dataset path. Every GaussianTrainConfig field the hosts set is either honoured
+// or named in the one-time "ignored" line of report_config().
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdarg>
@@ -22,6 +28,7 @@
 #include "../../include/dvs_raster.h"
 #include "../../include/dvs_scene.h"
 #include "../../include/dvs_train.h"
+#include "../../include/dvs_comm.h"
 #include "ply_io.hpp"
 
 namespace {
@@ -38,6 +45,26 @@ void logf_(const char* fmt, ...) {
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr ": ") + hipGetErrorString(e_)); } while (0)
 #define DVS_OR_THROW(expr)                                                                          \
     do { int r_ = (expr); if (r_ != DVS_OK) throw std::runtime_error(std::string(#expr ": ") + dvs_last_error()); } while (0)
+
+// training images kept as 8 bits per channel when packLevel has PackF32ToU8 (gs_train.cpp:91-96: the reference's VRAM saver):
+// a quarter of the HBM footprint per view, expanded into one fp32 staging image right before the loss
+__global__ void k_pack_u8(const float* __restrict__ src, uint8_t* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (uint8_t)fminf(255.f, fmaxf(0.f, rintf(src[i] * 255.f)));
+}
+__global__ void k_unpack_u8(const uint8_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i] * (1.0f / 255.0f);
+}
+// useMask (main.cpp:69-70): pixels outside the mask carry no loss gradient; mask [H*W] in {0,1}, dL planar [3,H,W]
+__global__ void k_mask_mul(float* __restrict__ dL, const float* __restrict__ mask, size_t P) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * P) dL[i] *= mask[i % P];
+}
+__global__ void k_norm2(const float* __restrict__ v2, float* __restrict__ out2, int n) {      // (x, y) -> (|v|, 0)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float x = v2[2 * i], y = v2[2 * i + 1]; out2[2 * i] = sqrtf(x * x + y * y); out2[2 * i + 1] = 0.f; }
+}
 
 struct Lcg {       // tiny deterministic noise source for the synthetic initialisation
     uint64_t s;
@@ -59,6 +86,13 @@ struct GaussianTrainerScene::Impl {
     float* d_param[6] = {}; float* d_grad[6] = {}; float* d_m[6] = {}; float* d_v[6] = {};
     float* d_param2[6] = {}; float* d_m2[6] = {}; float* d_v2[6] = {};       // densification writes old -> new, then the sets swap
     float* d_absgrad = nullptr;
+    float* d_grad_flat = nullptr; size_t grad_floats = 0;                    // the six gradient groups live in ONE buffer: one all-reduce
+    float* d_mean2d = nullptr;                                               // dL/dmean2D (ADC statistic when useAbsGrad is off)
+    dvs_comm* comm = nullptr; int rank = 0, world = 1;                       // data-parallel replicas (include/dvs_comm.h)
+    std::vector<uint8_t*> d_targets_u8; float* d_target_f32 = nullptr;       // packLevel & PackF32ToU8
+    std::vector<float*> d_masks;                                             // useMask
+    std::vector<float> init_host[6];                                         // initial splats (resetGaussian, getPoints3D)
+    bool terminate = false, pruning = false;
     int cap = 0;                                                             // array capacity in splats (cfg.capMax)
     float* d_grad_accum = nullptr; float* d_denom = nullptr; int* d_max_radii = nullptr;
     uint8_t* d_action = nullptr; uint32_t* d_offsets = nullptr; uint32_t* d_dscratch = nullptr; uint64_t* d_newcount = nullptr;
@@ -80,8 +114,15 @@ struct GaussianTrainerScene::Impl {
     void release() {
         if (device >= 0) (void)hipSetDevice(device);
         for (int g = 0; g < 6; ++g) {
-            for (float** p : {&d_param[g], &d_grad[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+            for (float** p : {&d_param[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+            d_grad[g] = nullptr;                                             // slices of d_grad_flat
         }
+        for (uint8_t* t : d_targets_u8) (void)hipFree(t);
+        d_targets_u8.clear();
+        for (float* t : d_masks) (void)hipFree(t);
+        d_masks.clear();
+        for (float** p : {&d_grad_flat, &d_mean2d, &d_target_f32}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (comm) { dvs_comm_destroy(comm); comm = nullptr; }
         for (void** p : {(void**)&d_grad_accum, (void**)&d_denom, (void**)&d_max_radii, (void**)&d_action, (void**)&d_offsets,
                          (void**)&d_dscratch, (void**)&d_newcount, &d_mcmc}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         for (float* t : d_targets) (void)hipFree(t);
@@ -105,9 +146,16 @@ struct GaussianTrainerScene::Impl {
     }
     void alloc_params(int count, int capacity, const std::vector<float> init[6]) {
         n = count; cap = std::max(capacity, count);
+        grad_floats = 0;
+        size_t goff[6];
+        for (int g = 0; g < 6; ++g) { goff[g] = grad_floats; grad_floats += (dev_floats_for(g, cap) + 3) & ~(size_t)3; }     // 16-B aligned groups
+        HIP_OR_THROW(hipMalloc((void**)&d_grad_flat, grad_floats * sizeof(float) + 16));
+        HIP_OR_THROW(hipMemset(d_grad_flat, 0, grad_floats * sizeof(float)));
+        for (int g = 0; g < 6; ++g) d_grad[g] = d_grad_flat + goff[g];
+        HIP_OR_THROW(hipMalloc((void**)&d_mean2d, (size_t)cap * 2 * sizeof(float) + 4));
         for (int g = 0; g < 6; ++g) {
             const size_t bytes = dev_floats_for(g, cap) * sizeof(float);
-            for (float** p : {&d_param[g], &d_grad[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) {
+            for (float** p : {&d_param[g], &d_m[g], &d_v[g], &d_param2[g], &d_m2[g], &d_v2[g]}) {
                 HIP_OR_THROW(hipMalloc((void**)p, bytes ? bytes : 4));
                 HIP_OR_THROW(hipMemset(*p, 0, bytes));         // pad lanes of the last tile are never written: keep them zero
             }
@@ -129,6 +177,10 @@ struct GaussianTrainerScene::Impl {
     }
     void densify(int it);
     void densify_mcmc(int it);
+    void prune_light(int it);
+    void report_config() const;
+    void sync_stats();
+    const float* target_for(int ci);
     bool mcmc() const { return cfg.densifyStrategy == 1; }
     dvs_splats splats() const {
         dvs_splats s{};
@@ -158,6 +210,50 @@ struct GaussianTrainerScene::Impl {
     bool load_synthetic(const std::string& spec_str);
 };
 
+// the fp32 target image of camera ci on the device (expands the 8-bit copy when packLevel has PackF32ToU8)
+const float* GaussianTrainerScene::Impl::target_for(int ci) {
+    if (!(cfg.packLevel & PackF32ToU8)) return d_targets[ci];
+    const size_t img = 3 * (size_t)W * H;
+    hipLaunchKernelGGL(k_unpack_u8, dim3((unsigned)((img + 255) / 256)), dim3(256), 0, stream, d_targets_u8[ci], d_target_f32, img);
+    return d_target_f32;
+}
+
+// One line per decision: which GaussianTrainConfig fields this build honours and which it ignores (gs_train.cpp:50-103 sets them all).
+void GaussianTrainerScene::Impl::report_config() const {
+    if (rank != 0) return;
+    static const char* strat[3] = {"ADC (clone / split / prune)", "MCMC (relocation + growth)", "ADC+ (ADC on abs-grad statistics with revised opacity)"};
+    logf_("config: densifyStrategy %d = %s; pruneStrategy %d (%s) every %d steps after refineStopIter %d; capMax %d; packLevel %d (%s%s); "
+          "useMask %d; useAbsGrad %d; mipAntiliased %d; visibleAdam %d; singleCamera %d; progressiveTrain %d; world %d",
+          cfg.densifyStrategy, strat[std::min(2, std::max(0, cfg.densifyStrategy))], cfg.pruneStrategy,
+          cfg.pruneStrategy > 0 ? "light prune: opacity < pruneOpacity or scale > pruneScale3d" : "off", cfg.pruneInterval, cfg.refineStopIter,
+          cfg.capMax, cfg.packLevel, (cfg.packLevel & PackF32ToU8) ? "PackF32ToU8: 8-bit training views" : "fp32 training views",
+          (cfg.packLevel & PackTileID) ? ", PackTileID: always on here (tile ids are sorted as 8-bit digits of a 32-bit key)" : "",
+          (int)cfg.useMask, (int)cfg.useAbsGrad, (int)cfg.mipAntiliased, (int)cfg.visibleAdam, (int)cfg.singleCamera, (int)cfg.progressiveTrain, world);
+    std::string ign;
+    if (cfg.modelType != 0) ign += " modelType(only 3DGS)";
+    if (cfg.cullSH) ign += " cullSH";
+    if (cfg.pixelGradScale) ign += " pixelGradScale";
+    if (cfg.bestQuality) ign += " bestQuality";
+    if (cfg.normalConsistencyLoss) ign += " normalConsistencyLoss(2DGS)";
+    if (cfg.enableBg) ign += " enableBg";
+    if (cfg.enableFocusRegion) ign += " enableFocusRegion";
+    if (cfg.exportMesh) ign += " exportMesh";
+    if (cfg.outputSparsePoints) ign += " outputSparsePoints";
+    if (cfg.resolutionSchedule) ign += " resolutionSchedule";
+    if (cfg.maxImageCount) ign += " maxImageCount";
+    if (!cfg.cameraPosePath.empty() || !cfg.pointCloudPath.empty()) ign += " cameraPosePath/pointCloudPath(dataset ingestion)";
+    if (cfg.visibleAdam && world > 1) ign += " visibleAdam(off with WORLD_SIZE > 1: the visible set differs per rank)";
+    if (!ign.empty()) logf_("config: IGNORED by this build:%s", ign.c_str());
+}
+
+// data parallel: the densification statistics are per-view sums / maxima — make them global before a refinement decision
+void GaussianTrainerScene::Impl::sync_stats() {
+    if (!comm) return;
+    DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(comm, stream, d_grad_accum, (size_t)n));
+    DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(comm, stream, d_denom, (size_t)n));
+    DVS_OR_THROW(dvs_comm_all_reduce_max_i32(comm, stream, d_max_radii, (size_t)n));
+}
+
 bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     // "synthetic:N=100000,W=800,H=800,cams=8,sh=3,seed=1"
     std::map<std::string, double> kv = {{"N", 100000}, {"W", 800}, {"H", 800}, {"cams", 8}, {"sh", 3}, {"seed", 1}};
@@ -181,7 +277,7 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     std::vector<float> gt[6];
     for (int g = 0; g < 6; ++g) gt[g].resize((size_t)spec.n * kWidth[g]);
     DVS_OR_THROW(dvs_synth_splats(&spec, gt[0].data(), gt[1].data(), gt[2].data(), gt[3].data(), gt[4].data(), gt[5].data()));
-    const int capacity = std::max(spec.n, cfg.capMax > 0 ? std::min(cfg.capMax, std::max(spec.n * 3, 4096)) : spec.n);
+    const int capacity = std::max(spec.n, cfg.capMax);          // --capMax is the array capacity (gs_train.cpp:89); 1.9 KB of HBM per splat
     ctx = dvs_create(device, (size_t)capacity, W, H);
     if (!ctx) throw std::runtime_error(std::string("dvs_create: ") + dvs_last_error());
     // ground-truth views: render the generating scene once per camera
@@ -201,8 +297,30 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
         float* t = nullptr;
         HIP_OR_THROW(hipMalloc((void**)&t, img * sizeof(float)));
         DVS_OR_THROW(dvs_raster_forward(ctx, stream, &sp, &cam, &opts, t, nullptr, nullptr));
-        cams.push_back(cam); d_targets.push_back(t);
+        cams.push_back(cam);
+        if (cfg.packLevel & PackF32ToU8) {                     // keep the view as 8 bits per channel, expand per step (target_for)
+            uint8_t* t8 = nullptr;
+            HIP_OR_THROW(hipMalloc((void**)&t8, img));
+            hipLaunchKernelGGL(k_pack_u8, dim3((unsigned)((img + 255) / 256)), dim3(256), 0, stream, t, t8, img);
+            HIP_OR_THROW(hipStreamSynchronize(stream));
+            (void)hipFree(t);
+            d_targets_u8.push_back(t8); d_targets.push_back(nullptr);
+        } else {
+            d_targets.push_back(t);
+        }
+        if (cfg.useMask) {                                     // synthetic mask: an ellipse inscribed in the image (no dataset masks here)
+            std::vector<float> mk((size_t)W * H);
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+                const float u = (x + 0.5f) / W * 2.f - 1.f, v = (y + 0.5f) / H * 2.f - 1.f;
+                mk[(size_t)y * W + x] = (u * u + v * v <= 1.f) ? 1.f : 0.f;
+            }
+            float* dm = nullptr;
+            HIP_OR_THROW(hipMalloc((void**)&dm, mk.size() * sizeof(float)));
+            HIP_OR_THROW(hipMemcpy(dm, mk.data(), mk.size() * sizeof(float), hipMemcpyHostToDevice));
+            d_masks.push_back(dm);
+        }
     }
+    if (cfg.packLevel & PackF32ToU8) HIP_OR_THROW(hipMalloc((void**)&d_target_f32, img * sizeof(float)));
     HIP_OR_THROW(hipStreamSynchronize(stream));
     {   // scene extent = 1.1 x the largest distance of a camera centre from their mean (the usual "cameras_extent"); a single
         // camera or a tiny rig falls back to half the depth range of the synthetic slab
@@ -235,7 +353,8 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
             for (int k = 0; k < 3; ++k) init[P_SCALE][3 * i + k] += 0.15f * r.sym();
         }
     }
-    for (int g = 0; g < 6; ++g) upload(g, init[g]);
+    for (int g = 0; g < 6; ++g) { upload(g, init[g]); init_host[g] = init[g]; }
+    report_config();
     if (cfg.verbose) logf_("synthetic scene: %d splats, %d cameras @ %dx%d, SH degree %d%s", spec.n, spec.n_cams, W, H, sh_max, resumed ? " (resumed)" : "");
     return true;
 }
@@ -259,6 +378,7 @@ void GaussianTrainerScene::Impl::densify_mcmc(int it) {
 
 // clone / split / prune between two iterations (densifyStrategy 0 ADC; 2 "ADC+" is served by the same rule)
 void GaussianTrainerScene::Impl::densify(int it) {
+    sync_stats();
     dvs_densify_params prm{};
     prm.grad_threshold = cfg.growGrad2d;
     prm.scale_threshold = 0.01f * extent;                       // percent_dense x extent
@@ -268,7 +388,7 @@ void GaussianTrainerScene::Impl::densify(int it) {
     prm.max_screen_radius = after_reset && it < cfg.refineScale2dStopIter                    // `pruneScale2d` (fraction of the image size)
                                 ? std::max(1, (int)(cfg.pruneScale2d * (float)std::max(W, H))) : 0;
     prm.cap_max = cap; prm.seed = (uint32_t)it; prm.shn_layout = DVS_SHN_TILED;
-    prm.revised_opacity = cfg.revisedOpacity ? 1 : 0;
+    prm.revised_opacity = (cfg.revisedOpacity || cfg.densifyStrategy == 2) ? 1 : 0;      // ADC+ always uses the revised opacity of the copies
     uint64_t new_n = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         DVS_OR_THROW(dvs_densify_plan(stream, n, d_param[P_OPA], d_param[P_SCALE], d_grad_accum, d_denom, d_max_radii, &prm, d_action,
@@ -296,6 +416,43 @@ void GaussianTrainerScene::Impl::densify(int it) {
     host_valid = false;
 }
 
+// pruneStrategy > 0 ("Light Gaussian Prune" in the reference's log, screenshots/cli_example.png): after refinement has stopped, every
+// pruneInterval steps splats that became transparent (opacity < pruneOpacity) or oversized (scale > pruneScale3d x extent) are removed
+// and the arrays compacted; no growth. Runs replicated (deterministic) on every rank.
+void GaussianTrainerScene::Impl::prune_light(int it) {
+    pruning = true;
+    dvs_densify_params prm{};
+    prm.grad_threshold = 3.0e38f;                               // never clone / split
+    prm.scale_threshold = 0.01f * extent;
+    prm.min_opacity = std::max(cfg.pruneOpacity, cfg.min_opacity);       // --minOpacity is the only opacity threshold the CLI exposes
+    prm.max_world_scale = cfg.pruneScale3d * extent;
+    prm.max_screen_radius = 0;
+    prm.cap_max = cap; prm.seed = (uint32_t)it; prm.shn_layout = DVS_SHN_TILED; prm.revised_opacity = 0;
+    HIP_OR_THROW(hipMemsetAsync(d_grad_accum, 0, (size_t)cap * 4, stream));
+    HIP_OR_THROW(hipMemsetAsync(d_denom, 0, (size_t)cap * 4, stream));
+    HIP_OR_THROW(hipMemsetAsync(d_max_radii, 0, (size_t)cap * 4, stream));
+    uint64_t new_n = 0;
+    DVS_OR_THROW(dvs_densify_plan(stream, n, d_param[P_OPA], d_param[P_SCALE], d_grad_accum, d_denom, d_max_radii, &prm, d_action,
+                                  d_offsets, d_dscratch, d_newcount));
+    HIP_OR_THROW(hipMemcpyAsync(&new_n, d_newcount, 8, hipMemcpyDeviceToHost, stream));
+    HIP_OR_THROW(hipStreamSynchronize(stream));
+    if (new_n > 0 && new_n < (uint64_t)n) {
+        for (int set = 0; set < 3; ++set) {
+            float** src = set == 0 ? d_param : (set == 1 ? d_m : d_v);
+            float** dst = set == 0 ? d_param2 : (set == 1 ? d_m2 : d_v2);
+            const float* s6[6] = {src[0], src[1], src[2], src[3], src[4], src[5]};
+            HIP_OR_THROW(hipMemsetAsync(dst[P_SHN], 0, dev_floats_for(P_SHN, (int)new_n) * sizeof(float), stream));
+            DVS_OR_THROW(dvs_densify_apply(stream, n, d_action, d_offsets, &prm, set == 0 ? 0 : 1, s6, dst, (int)new_n));
+            for (int g = 0; g < 6; ++g) std::swap(src[g], dst[g]);
+        }
+        if (cfg.verbose && rank == 0) logf_("light prune @%d: %d -> %llu splats", it, n, (unsigned long long)new_n);
+        n = (int)new_n;
+        HIP_OR_THROW(hipMemsetAsync(d_grad_flat, 0, grad_floats * sizeof(float), stream));
+        host_valid = false;
+    }
+    pruning = false;
+}
+
 GaussianTrainerScene::GaussianTrainerScene(const GaussianTrainConfig& cfg, int loadItr) : impl_(new Impl()) {
     impl_->cfg = cfg;
     impl_->loadItr = loadItr;
@@ -307,6 +464,16 @@ GaussianTrainerScene::GaussianTrainerScene(const GaussianTrainConfig& cfg, int l
     impl_->device %= count;
     HIP_OR_THROW(hipSetDevice(impl_->device));
     HIP_OR_THROW(hipStreamCreate(&impl_->stream));
+    // data parallel when launched as one process per GPU (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); DVS_FORCE_COMM=1 runs the
+    // collectives on a 1-rank communicator too (single-GPU proof of the RCCL path)
+    const char* ws = getenv("WORLD_SIZE"); const char* rk = getenv("RANK"); const char* force = getenv("DVS_FORCE_COMM");
+    const int world = ws ? atoi(ws) : 1;
+    if (world > 1 || (force && force[0] == '1')) {
+        impl_->comm = dvs_comm_create(impl_->device, rk ? atoi(rk) : 0, std::max(1, world), nullptr, 0);
+        if (!impl_->comm) throw std::runtime_error(std::string("gstrain: dvs_comm_create failed: ") + dvs_last_error());
+        impl_->rank = dvs_comm_rank(impl_->comm); impl_->world = dvs_comm_world(impl_->comm);
+        logf_("rank %d of %d on device %d: RCCL communicator up", impl_->rank, impl_->world, impl_->device);
+    }
 }
 GaussianTrainerScene::~GaussianTrainerScene() = default;
 
@@ -338,38 +505,61 @@ void GaussianTrainerScene::trainStep() {
     Impl& m = *impl_;
     if (!m.ctx || m.cams.empty()) throw std::runtime_error("trainStep before loadTrainData");
     HIP_OR_THROW(hipSetDevice(m.device));
-    // camera: xorshift over the view list (one view per iteration, as the reference's trainStep renders one camera)
-    m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
-    const int ci = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
+    // cameras: one xorshift stream shared by all ranks; an iteration draws `world` views and rank r renders the r-th (one view per
+    // GPU and iteration, as the reference's trainStep renders one camera)
+    int ci = 0;
+    for (int r = 0; r < m.world; ++r) {
+        m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
+        if (r == m.rank) ci = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
+    }
     const int it = m.step + 1;
     const int deg = m.cfg.progressiveTrain ? std::min(m.sh_max, m.step / 1000) : m.sh_max;   // SH bands unlocked every 1000 steps
-    dvs_opts opts{deg, m.cfg.mipAntiliased ? 1 : 0, m.cfg.useAbsGrad ? 1 : 0, 0, DVS_SHN_TILED};
+    const bool mcmc = m.mcmc();
+    const bool adc_plus = m.cfg.densifyStrategy == 2;
+    const bool absgrad = m.cfg.useAbsGrad || adc_plus;                                        // ADC+ always splits on the abs-grad statistic
+    const bool refining = it < m.cfg.refineStopIter;
+    dvs_opts opts{};
+    opts.sh_degree = deg; opts.antialias = m.cfg.mipAntiliased ? 1 : 0; opts.absgrad = absgrad ? 1 : 0; opts.accumulate = 0;
+    opts.shn_layout = DVS_SHN_TILED;
+    opts.grad_mode = DVS_GRAD_LINEAGE;          // the backward of the lineage the reference credits (README.md:95)
     const dvs_splats sp = m.splats();
     DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, &m.fwd, nullptr));
     // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25); its gradient goes straight into d_dL
+    const float* target = m.target_for(ci);
     const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
     HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, 2 * DVS_SSIM_SLOTS * sizeof(float), m.stream));
     if (w_ssim > 0.f) {     // SSIM maps, then the L1 and SSIM gradients in one pass over the image
-        DVS_OR_THROW(dvs_ssim_forward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
+        DVS_OR_THROW(dvs_ssim_forward(m.stream, m.d_out, target, m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
                                       m.d_loss + DVS_SSIM_SLOTS));
-        DVS_OR_THROW(dvs_loss_l1_ssim_backward(m.stream, m.d_out, m.d_targets[ci], m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1],
+        DVS_OR_THROW(dvs_loss_l1_ssim_backward(m.stream, m.d_out, target, m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1],
                                                m.d_ssim_maps[2], w_ssim, m.d_dL, m.d_loss));
     } else {
-        DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, m.d_targets[ci], 3 * (size_t)m.W * m.H, 1.f, m.d_dL, m.d_loss));
+        DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, target, 3 * (size_t)m.W * m.H, 1.f, m.d_dL, m.d_loss));
+    }
+    if (m.cfg.useMask && !m.d_masks.empty()) {
+        const size_t P = (size_t)m.W * m.H;
+        hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)((3 * P + 255) / 256)), dim3(256), 0, m.stream, m.d_dL, m.d_masks[ci], P);
     }
     dvs_splat_grads g{};
     g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
-    g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = m.cfg.useAbsGrad ? m.d_absgrad : nullptr; g.mean2d = nullptr;
+    g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = absgrad ? m.d_absgrad : nullptr;
+    g.mean2d = (!absgrad && !mcmc && refining) ? m.d_mean2d : nullptr;      // ADC without abs-grad: the norm of dL/dmean2D is the statistic
     DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
-    const bool mcmc = m.mcmc();
-    const bool refining = (mcmc || m.cfg.useAbsGrad) && it < m.cfg.refineStopIter;
     if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule)
         DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
-    if (refining && !mcmc)      // densification statistics of this view
-        DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, m.d_absgrad, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
-    // Adam, per-group learning rates (names gs_train.cpp:52-57; position lr decays exponentially init -> final)
+    if (refining && !mcmc) {    // densification statistics of this view; summed over the ranks in densify()
+        const float* stat = m.d_absgrad;
+        if (!absgrad) {         // the standard rule: |dL/dmean2D| of the view, threshold growGrad2d (0.0002)
+            hipLaunchKernelGGL(k_norm2, dim3((unsigned)((m.n + 255) / 256)), dim3(256), 0, m.stream, m.d_mean2d, m.d_mean2d, m.n);
+            stat = m.d_mean2d;
+        }
+        DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, stat, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
+    }
+    // data parallel: ONE sum-all-reduce of the 59-float gradient rows of all six groups (they live in one buffer) over RCCL / xGMI
+    if (m.comm) DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.stream, m.d_grad_flat, m.grad_floats));
+    // Adam, per-group learning rates (names gs_train.cpp:52-57; position lr decays exponentially init -> final, scaled by the scene extent)
     const float t = std::min(1.0f, (float)m.step / (float)std::max(1, m.cfg.numIters));
-    const float lr_pos = std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
+    const float lr_pos = m.extent * std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
     const float lr[6] = {lr_pos, m.cfg.featurelr, m.cfg.featurelr / 20.f, m.cfg.opacitylr, m.cfg.scalinglr, m.cfg.rotationlr};
     // one launch for the six groups; shN chunks above the active SH degree have g = m = v = 0 (Adam is the identity there)
     static const int width[6] = {3, 3, 45, 1, 3, 4};
@@ -380,14 +570,19 @@ void GaussianTrainerScene::trainStep() {
         if (k == P_SHN) ag[k].active_chunks = deg >= 3 ? 0 : (3 * ((deg + 1) * (deg + 1) - 1) + 3) / 4;
     }
     if (deg == 0) ag[P_SHN].count = 0;
-    DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, m.cfg.visibleAdam ? m.fwd.radii : nullptr, m.n));
+    const bool visible_only = m.cfg.visibleAdam && m.world == 1;       // per-rank visibility would let the replicas drift apart
+    DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, visible_only ? m.fwd.radii : nullptr, m.n));
     if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
         DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
                                         m.cfg.noiselr * lr_pos, (uint32_t)it));
     if (refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0) { if (mcmc) m.densify_mcmc(it); else m.densify(it); }
     if (refining && !mcmc && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0)
         DVS_OR_THROW(dvs_reset_opacity(m.stream, m.n, m.d_param[P_OPA], 0.01f, m.d_m[P_OPA], m.d_v[P_OPA]));
-    if (m.cfg.verbose && (m.step % 100 == 0))          // same line the editor logs (application/editor/source/editor.cpp:1554)
+    if (!refining && m.cfg.pruneStrategy > 0 && m.cfg.pruneInterval > 0 && it % m.cfg.pruneInterval == 0) {
+        m.prune_light(it);
+        pruenIteraions.push_back(it);
+    }
+    if (m.cfg.verbose && m.rank == 0 && (m.step % 100 == 0))          // same line the editor logs (application/editor/source/editor.cpp:1554)
         logf_("Iteraions %d, loss : %f", m.step, (double)getCurrentLoss());
     m.step = it;
     curIteration = it;
@@ -397,6 +592,7 @@ void GaussianTrainerScene::trainStep() {
 
 void GaussianTrainerScene::saveGaussianModel() {
     Impl& m = *impl_;
+    if (m.rank != 0) return;                 // the replicas are identical: one file
     m.fetch_host();
     const std::string file = m.model_file(m.step);
     std::error_code ec;
@@ -409,6 +605,112 @@ void GaussianTrainerScene::saveGaussianModel() {
     else if (m.cfg.verbose) logf_("saved %d splats to %s", m.n, file.c_str());
 }
 void GaussianTrainerScene::exportMesh(const std::string&) { logf_("export_mesh: mesh extraction is outside this build's scope"); }
+void GaussianTrainerScene::exportSparsePointCloud(const std::string& path) {
+    Impl& m = *impl_;
+    m.fetch_host();
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) { logf_("exportSparsePointCloud: cannot open %s", path.c_str()); return; }
+    fprintf(f, "ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n", m.n);
+    for (int i = 0; i < m.n; ++i) fprintf(f, "%g %g %g\n", m.host[P_POS][3 * i], m.host[P_POS][3 * i + 1], m.host[P_POS][3 * i + 2]);
+    fclose(f);
+}
+void GaussianTrainerScene::saveCameraDatas(const std::string& path) {
+    Impl& m = *impl_;
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) { logf_("saveCameraDatas: cannot open %s", path.c_str()); return; }
+    for (size_t c = 0; c < m.cams.size(); ++c) {
+        const dvs_camera& k = m.cams[c];
+        fprintf(f, "%zu %d %d %g %g %g %g %g", c, k.width, k.height, k.focal_x, k.focal_y, k.campos[0], k.campos[1], k.campos[2]);
+        for (int e = 0; e < 16; ++e) fprintf(f, " %g", k.view[e]);
+        fputc('\n', f);
+    }
+    fclose(f);
+}
+bool GaussianTrainerScene::isTerminate() const { return impl_->terminate; }
+void GaussianTrainerScene::terminate() { impl_->terminate = true; }
+bool GaussianTrainerScene::isPruningSplat() const { return impl_->pruning; }
+void GaussianTrainerScene::resetGaussian() {
+    Impl& m = *impl_;
+    if (!m.ctx || m.init_host[P_OPA].empty()) return;
+    HIP_OR_THROW(hipSetDevice(m.device));
+    HIP_OR_THROW(hipStreamSynchronize(m.stream));
+    m.n = (int)m.init_host[P_OPA].size();
+    for (int g = 0; g < 6; ++g) {
+        const size_t bytes = m.dev_floats_for(g, m.cap) * sizeof(float);
+        for (float** p : {&m.d_param[g], &m.d_m[g], &m.d_v[g]}) HIP_OR_THROW(hipMemset(*p, 0, bytes));
+        m.upload(g, m.init_host[g]);
+    }
+    HIP_OR_THROW(hipMemset(m.d_grad_flat, 0, m.grad_floats * sizeof(float)));
+    m.reset_stats();
+    m.step = 0; curIteration = 0; pruenIteraions.clear();
+    m.host_valid = false;
+    m.status = TrainingStatus::Training;
+    m.t0 = std::chrono::steady_clock::now();
+}
+void GaussianTrainerScene::setDensifyStrategy(int strategy) { impl_->cfg.densifyStrategy = std::min(2, std::max(0, strategy)); impl_->report_config(); }
+void GaussianTrainerScene::setModelPath(const std::string& path) { impl_->cfg.modelPath = path; }
+void GaussianTrainerScene::updateFocusRegion(const dvs_types::Vec3& position, const dvs_types::Vec3& rotation, const dvs_types::Vec3& scale) {
+    focus_region_position = position; focus_region_rotation = rotation; focus_region_scale = scale;     // stored; enableFocusRegion is not used by the trainer
+}
+std::string GaussianTrainerScene::getCurrentTrainingPhaseName() const {
+    switch (impl_->status) {
+        case TrainingStatus::Loading_Prepare: return "Loading";
+        case TrainingStatus::Colmap_Sfm: return "SfM";
+        case TrainingStatus::Preprocess_Done: return "Preprocess done";
+        case TrainingStatus::Training: return impl_->pruning ? "Pruning" : "Training";
+        case TrainingStatus::Training_Done: return "Done";
+        case TrainingStatus::Loading_Failed: return "Failed";
+        default: return "GS2Mesh";
+    }
+}
+float GaussianTrainerScene::getProgressOnCurrentPhase() const {
+    return impl_->cfg.numIters > 0 ? std::min(1.f, (float)impl_->step / (float)impl_->cfg.numIters) : 0.f;
+}
+double GaussianTrainerScene::getEstimateTrainingTime() const {
+    const double el = getTrainingElpasedTime();
+    return impl_->step > 0 ? el / impl_->step * std::max(0, impl_->cfg.numIters - impl_->step) : 0.0;
+}
+dvs_types::Mat4 GaussianTrainerScene::getCameraProjection(int i) const {
+    // perspective projection of the training camera (column-major, OpenGL clip conventions as the editor's Frustum expects)
+    dvs_types::Mat4 P{};
+    float* o = reinterpret_cast<float*>(&P);
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    if (i < 0 || i >= (int)impl_->cams.size()) return P;
+    const dvs_camera& k = impl_->cams[i];
+    const float zn = 0.2f, zf = 100.f;
+    o[0] = 1.f / k.tan_fovx; o[5] = 1.f / k.tan_fovy; o[10] = -(zf + zn) / (zf - zn); o[11] = -1.f; o[14] = -2.f * zf * zn / (zf - zn);
+    return P;
+}
+dvs_types::Quat GaussianTrainerScene::getCameraRotation(int i) const {
+    dvs_types::Quat q{};
+    if (i < 0 || i >= (int)impl_->cams.size()) return q;
+    const float* v = impl_->cams[i].view;          // view[c*4+r]: world -> camera; rotation R[r][c] = v[c*4+r]; camera -> world = R^T
+    const float R[3][3] = {{v[0], v[1], v[2]}, {v[4], v[5], v[6]}, {v[8], v[9], v[10]}};      // R^T rows
+    const float tr = R[0][0] + R[1][1] + R[2][2];
+    float w, x, y, z;
+    if (tr > 0.f) { const float s = std::sqrt(tr + 1.f) * 2.f; w = 0.25f * s; x = (R[2][1] - R[1][2]) / s; y = (R[0][2] - R[2][0]) / s; z = (R[1][0] - R[0][1]) / s; }
+    else if (R[0][0] > R[1][1] && R[0][0] > R[2][2]) { const float s = std::sqrt(1.f + R[0][0] - R[1][1] - R[2][2]) * 2.f; w = (R[2][1] - R[1][2]) / s; x = 0.25f * s; y = (R[0][1] + R[1][0]) / s; z = (R[0][2] + R[2][0]) / s; }
+    else if (R[1][1] > R[2][2]) { const float s = std::sqrt(1.f + R[1][1] - R[0][0] - R[2][2]) * 2.f; w = (R[0][2] - R[2][0]) / s; x = (R[0][1] + R[1][0]) / s; y = 0.25f * s; z = (R[1][2] + R[2][1]) / s; }
+    else { const float s = std::sqrt(1.f + R[2][2] - R[0][0] - R[1][1]) * 2.f; w = (R[1][0] - R[0][1]) / s; x = (R[0][2] + R[2][0]) / s; y = (R[1][2] + R[2][1]) / s; z = 0.25f * s; }
+    float* o = reinterpret_cast<float*>(&q);
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+    return q;
+}
+dvs_types::Vec3 GaussianTrainerScene::getCameraPos(int i) const {
+    dvs_types::Vec3 p{};
+    if (i < 0 || i >= (int)impl_->cams.size()) return p;
+    float* o = reinterpret_cast<float*>(&p);
+    for (int k = 0; k < 3; ++k) o[k] = impl_->cams[i].campos[k];
+    return p;
+}
+const std::vector<float>& GaussianTrainerScene::getPoints3D(int) { return impl_->init_host[P_POS]; }
+bool is_device_support_gstrain() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return false;
+    hipDeviceProp_t pr;
+    return hipGetDeviceProperties(&pr, 0) == hipSuccess && strstr(pr.gcnArchName, "gfx95") != nullptr;
+}
+bool is_driver_support() { int v = 0; return hipRuntimeGetVersion(&v) == hipSuccess && v > 0; }
 bool GaussianTrainerScene::isTrain() const { return impl_->training; }
 void GaussianTrainerScene::startTrain() { impl_->training = true; }
 void GaussianTrainerScene::pauseTrain() { impl_->training = false; }
@@ -453,14 +755,33 @@ __attribute__((visibility("default"))) void* create_splat(const GaussianTrainCon
     try { return new GaussianTrainerScene(config, loadItr); }
     catch (const std::exception& e) { logf_("create_splat: %s", e.what()); return nullptr; }
 }
+// The hosts have no try/catch around these dlsym'd calls (gs_train.cpp:152-179): nothing may escape across the C boundary. A
+// failure is logged, the scene is marked Loading_Failed / finished (so that the host's loop `get_cur_step >= maxIteration` ends).
+#define GSTRAIN_GUARD(name_, scene, body)                                                                        \
+    try { body; } catch (const std::exception& e) {                                                               \
+        logf_("%s failed: %s", name_, e.what());                                                                    \
+        if (scene) { scene->setTrainingStatus(GaussianTrainerScene::TrainingStatus::Loading_Failed); scene->terminate(); } \
+    } catch (...) { logf_("%s failed: unknown exception", name_); if (scene) scene->terminate(); }
 __attribute__((visibility("default"))) bool load_train_data(GaussianTrainerScene* scene, const std::string& path) {
-    return scene && scene->loadTrainData(path);
+    bool ok = false;
+    GSTRAIN_GUARD("load_train_data", scene, ok = scene && scene->loadTrainData(path));
+    return ok;
 }
-__attribute__((visibility("default"))) void train_step(GaussianTrainerScene* scene) { if (scene) scene->trainStep(); }
-__attribute__((visibility("default"))) int get_cur_step(GaussianTrainerScene* scene) { return scene ? scene->getCurrentIterations() : 0; }
-__attribute__((visibility("default"))) void save_splat_model(GaussianTrainerScene* scene) { if (scene) scene->saveGaussianModel(); }
-__attribute__((visibility("default"))) void export_mesh(GaussianTrainerScene* scene) { if (scene) scene->exportMesh(""); }
-__attribute__((visibility("default"))) void delete_splat(GaussianTrainerScene* scene) { delete scene; }
+__attribute__((visibility("default"))) void train_step(GaussianTrainerScene* scene) {
+    if (!scene || scene->isTerminate()) return;
+    GSTRAIN_GUARD("train_step", scene, scene->trainStep());
+}
+__attribute__((visibility("default"))) int get_cur_step(GaussianTrainerScene* scene) {
+    if (!scene) return 0;
+    // after a fatal error the step counter reports "done" so that the host's `while (get_cur_step < maxIteration)` loop terminates
+    return scene->isTerminate() ? std::max(scene->getCurrentIterations(), scene->maxIteriaons()) : scene->getCurrentIterations();
+}
+__attribute__((visibility("default"))) void save_splat_model(GaussianTrainerScene* scene) {
+    if (!scene) return;
+    GSTRAIN_GUARD("save_splat_model", scene, scene->saveGaussianModel());
+}
+__attribute__((visibility("default"))) void export_mesh(GaussianTrainerScene* scene) { if (scene) { GSTRAIN_GUARD("export_mesh", scene, scene->exportMesh("")); } }
+__attribute__((visibility("default"))) void delete_splat(GaussianTrainerScene* scene) { try { delete scene; } catch (...) { logf_("delete_splat failed"); } }
 __attribute__((visibility("default"))) void gstrain_destroy() {}
 __attribute__((visibility("default"))) const char* get_description() { return "gstrain: MI355X-native Gaussian-splat trainer (divshot_amd)"; }
 __attribute__((visibility("default"))) void* create_instance() { return nullptr; }

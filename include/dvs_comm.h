@@ -1,0 +1,44 @@
+/*
+ * dvs_comm.h — the thin C-ABI over RCCL for the data-parallel training step: one process per GPU, every rank a
+ * full replica of the splat parameter block, independent views sharded over the ranks, ONE exchange per iteration.
+ *
+ * What this replaces in the reference (fenghuayumo/DIVSHOT): nothing — the reference trainer is single-GPU and holds no collective
+ * call site (no nccl / rccl / mpi / gloo anywhere in its tree). This is the new functionality BASELINE.json's
+ * north_star asks for ("views shard one-per-GPU ... RCCL all-reduce of splat gradients over xGMI; host code stays C++").
+ * libgstrain.so uses it inside train_step() when WORLD_SIZE > 1 (divshot_amd/gstrain/gstrain.cpp).
+ *
+ * librccl is opened with dlopen() when the first communicator is created, so libdvsraster.so has no load-time dependency on it.
+ * Bootstrap: rank 0 creates the RCCL unique id and serves it over TCP on master_addr:master_port (the rendezvous address every
+ * launcher exports as MASTER_ADDR / MASTER_PORT); the other ranks connect and read it. Plain C, int status codes as dvs_raster.h.
+ */
+#ifndef DVS_COMM_H
+#define DVS_COMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dvs_comm dvs_comm;
+
+/* Create the communicator of this process on HIP device `device`. world < 1: rank / world / master are read from the environment
+ * (RANK, WORLD_SIZE, MASTER_ADDR default 127.0.0.1, MASTER_PORT default 29500). A 1-rank communicator is valid (every collective is
+ * then the identity, executed by RCCL all the same). Returns NULL on failure (dvs_last_error). Blocks until all ranks have joined. */
+dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_addr, int master_port);
+void      dvs_comm_destroy(dvs_comm* comm);
+int       dvs_comm_rank(const dvs_comm* comm);
+int       dvs_comm_world(const dvs_comm* comm);
+
+/* Collectives on DEVICE buffers, enqueued on `stream` (hipStream_t as void*), asynchronous. Counts are in elements. */
+int dvs_comm_all_reduce_sum_f32(dvs_comm* comm, void* stream, float* buf, size_t count);                 /* in place */
+int dvs_comm_all_reduce_max_i32(dvs_comm* comm, void* stream, int32_t* buf, size_t count);               /* in place */
+int dvs_comm_reduce_scatter_sum_f32(dvs_comm* comm, void* stream, const float* send /*[world*recv_count]*/, float* recv, size_t recv_count);
+int dvs_comm_all_gather_f32(dvs_comm* comm, void* stream, const float* send, float* recv /*[world*send_count]*/, size_t send_count);
+int dvs_comm_broadcast(dvs_comm* comm, void* stream, void* buf, size_t bytes, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVS_COMM_H */

@@ -16,6 +16,21 @@
 
 enum GSPackLevel : int { PackF32ToU8 = 1, PackTileID = 2 };   // bit flags (gs_train.cpp:91-96)
 
+// The editor passes glm values through a few members (editor.cpp:852-856, inspector_panel.cpp:909-933). This header does not depend on
+// glm: the PODs below are layout-compatible with glm::vec3 / glm::quat (x, y, z, w order) / glm::mat4 (column-major); a host that has
+// glm can build with -DDVS_TRAINER_USE_GLM and gets the glm types themselves.
+#ifdef DVS_TRAINER_USE_GLM
+#include <glm/glm.hpp>
+#include <glm/gtc/quaternion.hpp>
+namespace dvs_types { using Vec3 = glm::vec3; using Quat = glm::quat; using Mat4 = glm::mat4; }
+#else
+namespace dvs_types {
+struct Vec3 { float x = 0.f, y = 0.f, z = 0.f; };
+struct Quat { float x = 0.f, y = 0.f, z = 0.f, w = 1.f; };
+struct Mat4 { float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; };     // column-major
+}
+#endif
+
 struct GaussianTrainConfig {
     std::string sourcePath, modelPath = "../out_put/iteration", cameraPosePath, pointCloudPath;
     int numIters = 30000;                 // --maxIteration (main.cpp:19)
@@ -54,9 +69,25 @@ public:
     void trainStep();                                 // one iteration: sample camera -> raster fwd -> loss -> raster bwd -> Adam
     void saveGaussianModel();                         // PLY at modelPath (external/tinygsplat/tiny_gsplat.cpp:168-241 layout)
     void exportMesh(const std::string& path);         // out of scope: logs and returns
+    void exportSparsePointCloud(const std::string& path);   // editor.cpp:3535 — writes the splat centres as an ASCII PLY point cloud
+    void saveCameraDatas(const std::string& path);          // editor.cpp:3512 — one line per camera: centre, view matrix, intrinsics
     bool isTrain() const;
     void startTrain();
     void pauseTrain();
+    bool isTerminate() const;                         // editor.cpp:1603: the training thread leaves its loop when this is set
+    void terminate();
+    bool isPruningSplat() const;                      // editor.cpp:1551: true while a post-refinement prune pass is running
+    void resetGaussian();                             // inspector_panel.cpp:837,861,883,1017: back to the initial splats, step 0
+    void setDensifyStrategy(int strategy);            // inspector_panel.cpp:789 (0 ADC / 1 MCMC / 2 ADC+)
+    void setModelPath(const std::string& path);       // editor.cpp:2024
+    void updateFocusRegion(const dvs_types::Vec3& position, const dvs_types::Vec3& rotation, const dvs_types::Vec3& scale);   // inspector_panel.cpp:933
+    std::string getCurrentTrainingPhaseName() const;  // inspector_panel.cpp:997
+    float getProgressOnCurrentPhase() const;          // inspector_panel.cpp:999, scene_view_panel.cpp:1022 (0..1)
+    double getEstimateTrainingTime() const;           // inspector_panel.cpp:998: remaining seconds at the current rate
+    dvs_types::Mat4 getCameraProjection(int i) const; // editor.cpp:852-856: training cameras for the frustum gizmos
+    dvs_types::Quat getCameraRotation(int i) const;
+    dvs_types::Vec3 getCameraPos(int i) const;
+    const std::vector<float>& getPoints3D(int i);     // editor.cpp:1523: xyz of the initial point cloud (here: the initial splat centres)
     int  getCurrentIterations() const;
     float getCurrentLoss();                           // synchronises the training stream
     int& maxIteriaons();
@@ -78,11 +109,16 @@ public:
     bool ShowTrainView = false;
     int curIteration = 0;
     std::vector<int> pruenIteraions;
+    dvs_types::Vec3 focus_region_position, focus_region_rotation, focus_region_scale{1.f, 1.f, 1.f};   // editor.cpp:1486-1487
 
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
 };
+
+// free functions the editor calls before it starts training (editor.cpp:1534,1539)
+bool is_device_support_gstrain();     // a gfx950-class HIP device is visible
+bool is_driver_support();             // the HIP runtime initialises
 
 // C symbols the hosts resolve with dlsym (gs_train.cpp:24,105-109,144-150,178; plugin.cpp:89-111)
 extern "C" {

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = []
-    for h in ("dvs_raster.h", "dvs_scene.h", "dvs_train.h"):
+    for h in ("dvs_raster.h", "dvs_scene.h", "dvs_train.h", "dvs_comm.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names += re.findall(r"\b(dvs_[a-z0-9_]+)\s*\(", src)
