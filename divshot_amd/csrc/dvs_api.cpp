@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -222,6 +223,9 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
         (opts->shn_layout != DVS_SHN_ROWS && opts->shn_layout != DVS_SHN_TILED)) {
         g_last_error = "dvs_raster_forward: bad n / image size / sh_degree"; return DVS_ERR_INVALID;
     }
+    if (p->n > 0 && (((uintptr_t)p->pos | (uintptr_t)p->sh0 | (uintptr_t)p->shN | (uintptr_t)p->opacity | (uintptr_t)p->scale | (uintptr_t)p->rot) & 15u)) {
+        g_last_error = "dvs_raster_forward: parameter arrays must be 16-byte aligned"; return DVS_ERR_INVALID;
+    }
     if ((size_t)p->n > c->max_splats || cam->width > c->max_w || cam->height > c->max_h) {
         g_last_error = "dvs_raster_forward: exceeds the capacity given to dvs_create"; return DVS_ERR_CAPACITY;
     }
@@ -384,6 +388,10 @@ static int check_grads(const dvs_splats* p, const dvs_splat_grads* out, const ch
     if (p->n > 0 && (!out->pos || !out->opacity || !out->scale || !out->rot || ((!out->sh0 || !out->shN) && !out->dcolor))) {
         msg = std::string(who) + ": null gradient row pointer (sh0/shN may be NULL only when dcolor is given)";
         g_last_error = msg.c_str(); return DVS_ERR_INVALID;
+    }
+    if (p->n > 0 && (((uintptr_t)out->pos | (uintptr_t)out->sh0 | (uintptr_t)out->shN | (uintptr_t)out->opacity | (uintptr_t)out->scale |
+                      (uintptr_t)out->rot | (uintptr_t)out->absgrad2d | (uintptr_t)out->mean2d | (uintptr_t)out->dcolor) & 15u)) {
+        msg = std::string(who) + ": gradient arrays must be 16-byte aligned"; g_last_error = msg.c_str(); return DVS_ERR_INVALID;
     }
     return DVS_OK;
 }

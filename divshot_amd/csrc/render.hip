@@ -22,8 +22,9 @@
 // alpha = 1/255 ( d^T Q d = 2 ln(255 o), Q = conic ) against the four 8x8 quadrants of the tile (exact
 // ellipse-rectangle test). One ballot per quadrant turns the tests into 64-bit wave masks: the wave that
 // owns quadrant q later walks only the set bits (s_ff1 / s_flbit, scalar unit) and never spends a vector
-// instruction on a splat that cannot touch its pixels. The bound is inflated (1e-4 rel + 1e-3) so the
-// exact per-pixel alpha test — unchanged — decides every contribution: results are identical to a full walk.
+// instruction on a splat that cannot touch its pixels. The bound is inflated (1e-4 rel + 1e-3) and the rectangle minimum is
+// computed from non-negative terms only (see stage_batch), so the exact per-pixel alpha test — unchanged — decides every
+// contribution: results are identical to a full walk.
 struct __attribute__((aligned(16))) BatchLds {
     // Four 16-B-stride arrays (one address VGPR serves every read of a visit), packed so that each read is a full
     // ds_read_b128 or a ds_read_b32 (a 12-byte ds_read_b96 costs twice the LDS cycles of a b128):
@@ -53,22 +54,37 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         L.cog[t] = make_float4(co.x, co.y, co.z, col.y);
         L.bl[t].x = col.z;
         // The splat can reach alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o), d = pixel - mean.
-        // Minimise the convex form q over each quadrant's pixel rectangle (exact: origin inside -> 0, otherwise the
-        // minimum lies on one of the four edges) and keep the splat for that quadrant iff the minimum is within the bound.
-        const float bound = 2.0f * __logf(255.0f * co.w) * 1.0001f + 1e-3f;
+        // The minimum of the convex form over a quadrant's pixel rectangle is 0 if the mean lies inside, otherwise it lies on an edge
+        // FACING the mean: the nearer vertical edge when the mean is left / right of the rectangle's columns, the nearer horizontal
+        // edge when it is above / below. On the vertical line x:  q(x, y) = c (y - y*)^2 + x^2 det / c,  y* = -b x / c  (minimum at
+        // y = clamp(y*, y0, y1)); every term is non-negative, so — unlike a x^2 + 2 b x y + c y^2 evaluated directly — nothing cancels
+        // for thin, far-away splats, and det = a c - b^2 (which does cancel for them) is lowered by its own rounding bound: the
+        // minimum is never over-estimated and the exact per-pixel test decides every contribution.
+        const float bound = 1.3862943611f * __builtin_amdgcn_logf(255.0f * co.w) * 1.0001f + 1e-3f;       // 2 ln 2 log2(255 o)
         const float a = co.x, b = co.y, c = co.z;
-        const float nb_c = -b / c, nb_a = -b / a;
+        const float det = fmaxf(0.f, __builtin_fmaf(-2.4e-7f, a * c, a * c - b * b));
+        const float rc = __builtin_amdgcn_rcpf(c), ra = __builtin_amdgcn_rcpf(a);
+        const float det_c = det * rc, det_a = det * ra, nb_c = -b * rc, nb_a = -b * ra;
         const float ox = tile_x0 - xy.x, oy = tile_y0 - xy.y;                 // tile origin relative to the mean
-        auto qmin = [&](float x0, float x1, float y0, float y1) -> float {
-            if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
-            auto qf = [&](float x, float y) { return a * x * x + 2.f * b * x * y + c * y * y; };
-            const float e0 = qf(x0, fminf(fmaxf(nb_c * x0, y0), y1)), e1 = qf(x1, fminf(fmaxf(nb_c * x1, y0), y1));
-            const float e2 = qf(fminf(fmaxf(nb_a * y0, x0), x1), y0), e3 = qf(fminf(fmaxf(nb_a * y1, x0), x1), y1);
-            return fminf(fminf(e0, e1), fminf(e2, e3));
-        };
-        // NaN-safe: a failed comparison keeps the splat
-        qm = (!(qmin(ox, ox + 7.f, oy, oy + 7.f) > bound) ? 1u : 0u) | (!(qmin(ox + 8.f, ox + 15.f, oy, oy + 7.f) > bound) ? 2u : 0u) |
-             (!(qmin(ox, ox + 7.f, oy + 8.f, oy + 15.f) > bound) ? 4u : 0u) | (!(qmin(ox + 8.f, ox + 15.f, oy + 8.f, oy + 15.f) > bound) ? 8u : 0u);
+        float vy[2], vbase[2], hx[2], hbase[2];
+        bool vin[2], hin[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float x0 = ox + 8.f * (float)i, x1 = x0 + 7.f, y0 = oy + 8.f * (float)i, y1 = y0 + 7.f;
+            vin[i] = x0 <= 0.f && x1 >= 0.f; hin[i] = y0 <= 0.f && y1 >= 0.f;
+            const float xe = x0 > 0.f ? x0 : x1, ye = y0 > 0.f ? y0 : y1;
+            vy[i] = nb_c * xe; vbase[i] = vin[i] ? __builtin_inff() : xe * xe * det_c;
+            hx[i] = nb_a * ye; hbase[i] = hin[i] ? __builtin_inff() : ye * ye * det_a;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = q & 1, row = q >> 1;
+            const float x0 = ox + 8.f * (float)col, x1 = x0 + 7.f, y0 = oy + 8.f * (float)row, y1 = y0 + 7.f;
+            const float ty_ = fminf(fmaxf(vy[col], y0), y1) - vy[col], tx_ = fminf(fmaxf(hx[row], x0), x1) - hx[row];
+            const float ev = __builtin_fmaf(c * ty_, ty_, vbase[col]), eh = __builtin_fmaf(a * tx_, tx_, hbase[row]);
+            const float qmn = (vin[col] && hin[row]) ? 0.f : fminf(ev, eh);
+            qm |= !(qmn > bound) ? (1u << q) : 0u;                            // NaN-safe: a failed comparison keeps the splat
+        }
     }
     const uint64_t m0 = __ballot(qm & 1u), m1 = __ballot(qm & 2u), m2 = __ballot(qm & 4u), m3 = __ballot(qm & 8u);
     if ((t & 63) == 0) {

@@ -1,6 +1,7 @@
 // train_ops.hip — image loss gradient and fused Adam (include/dvs_train.h): HBM-streaming, 16 B per lane.
 // These are SURVEY.md §8(f) "next" rows 2-3, kept minimal; the reference's versions are in the closed plugin.
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include "../../include/dvs_train.h"
 #include "../../include/dvs_raster.h"
 
@@ -188,6 +189,7 @@ int dvs_adam_step_groups(void* stream, const dvs_adam_group* groups, int n_group
         const dvs_adam_group& a = groups[k];
         AdamGroupDev& d = G.g[G.n];
         if (a.count == 0) continue;
+        if (((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.m | (uintptr_t)a.v) & 15u) return DVS_ERR_INVALID;      // moved as float4
         if (!a.param || !a.grad || !a.m || !a.v || a.width < 1) return DVS_ERR_INVALID;
         const bool tiled = a.layout == DVS_SHN_TILED;
         if (tiled && (a.width != 45 || a.count % DVS_SHN_TILE_FLOATS != 0 || a.active_chunks < 0 || a.active_chunks > 12)) return DVS_ERR_INVALID;

@@ -32,21 +32,24 @@ def views_for_rank(n_views, rank, world):
 
 class GradBuffer:
     """Flat [n*59] gradient buffer with per-group views shaped like the parameter arrays.
-    flat_geom = the leading n*11 floats (pos, scale, rot, opacity); flat_sh = the trailing n*48 (sh0, shN)."""
+    flat_geom = the leading 11 floats per splat (pos, scale, rot, opacity); flat_sh = the trailing 48 (sh0, shN)."""
 
     def __init__(self, n, device, shn_tiled=False):
         self.n = n
         shn_floats = ((n + 63) // 64) * 64 * 48 if shn_tiled else n * 45     # DVS_SHN_TILED: whole 64-splat tiles, 48 floats/splat
-        self.flat = torch.zeros(n * (ROW_FLOATS - 45) + shn_floats, dtype=torch.float32, device=device)
-        self.views, off = {}, 0
+        # every group starts on a 16-byte boundary (the kernels move rot / shN / the 3-float groups as 16-B vectors, dvs_raster.h)
+        counts = {k: (shn_floats if k == "shN" else n * PARAM_WIDTH[k]) for k in FLAT_ORDER}
+        offs, off = {}, 0
         for k in FLAT_ORDER:
-            cnt = shn_floats if k == "shN" else n * PARAM_WIDTH[k]
-            v = self.flat[off:off + cnt]
+            offs[k] = off
+            off += (counts[k] + 3) & ~3
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.views = {}
+        for k in FLAT_ORDER:
+            v = self.flat[offs[k]:offs[k] + counts[k]]
             self.views[k] = v if (k == "shN" and shn_tiled) else v.view([n if d == -1 else d for d in SHAPES[k]])
-            off += cnt
-        assert off == self.flat.numel()
-        self.flat_geom = self.flat[: n * GEOM_FLOATS]
-        self.flat_sh = self.flat[n * GEOM_FLOATS:]
+        self.flat_geom = self.flat[: offs["sh0"]]          # pos, scale, rot, opacity (+ pad floats, always zero)
+        self.flat_sh = self.flat[offs["sh0"]:]
 
     def all_reduce(self, group=None, average=False):
         """Sum (or mean) ALL gradient rows over all ranks (236 B/splat on the wire). No-op without a process group."""
@@ -202,19 +205,28 @@ class ShardedAdam:
     def _adam(self, lr_scale=1.0):
         b1, b2 = self.betas
         t = self.step_no
+        def torch_adam(o, c, lr):                                      # the textbook recurrences on a sub-range, in torch
+            g = self.gshard[o:o + c]
+            self.m[o:o + c].mul_(b1).add_(g, alpha=1 - b1)
+            self.v[o:o + c].mul_(b2).addcmul_(g, g, value=1 - b2)
+            mh = self.m[o:o + c] / (1 - b1 ** t); vh = self.v[o:o + c] / (1 - b2 ** t)
+            self.pshard[o:o + c].sub_(lr * lr_scale * mh / (vh.sqrt() + self.eps))
         if self.p.is_cuda:
             from .train_ops import adam_step_groups
-            groups = [dict(param=self.pshard[o:o + c], grad=self.gshard[o:o + c], m=self.m[o:o + c], v=self.v[o:o + c], lr=lr * lr_scale, width=1)
-                      for o, c, lr in self.ranges]
+            groups = []
+            for o, c, lr in self.ranges:
+                head = min(c, (-o) % 4)                                # dvs_adam_step_groups moves float4: the kernel's part of a sub-range
+                if head:                                               # starts on a 16-byte boundary, the <= 3 floats before it go through torch
+                    torch_adam(o, head, lr)
+                if c > head:
+                    o2, c2 = o + head, c - head
+                    groups.append(dict(param=self.pshard[o2:o2 + c2], grad=self.gshard[o2:o2 + c2], m=self.m[o2:o2 + c2], v=self.v[o2:o2 + c2],
+                                       lr=lr * lr_scale, width=1))
             for i in range(0, len(groups), 8):
                 adam_step_groups(groups[i:i + 8], t, b1, b2, self.eps)
-        else:                                                           # CPU tensors (gloo tests): the textbook recurrences in torch
+        else:                                                           # CPU tensors (gloo tests)
             for o, c, lr in self.ranges:
-                g = self.gshard[o:o + c]
-                self.m[o:o + c].mul_(b1).add_(g, alpha=1 - b1)
-                self.v[o:o + c].mul_(b2).addcmul_(g, g, value=1 - b2)
-                mh = self.m[o:o + c] / (1 - b1 ** t); vh = self.v[o:o + c] / (1 - b2 ** t)
-                self.pshard[o:o + c].sub_(lr * lr_scale * mh / (vh.sqrt() + self.eps))
+                torch_adam(o, c, lr)
 
     def step(self, grads_flat, lr_scale=1.0):
         """One optimizer step on every rank's replica: after it, params_flat holds the updated parameters everywhere."""

@@ -19,6 +19,9 @@
  *   pos[N,3] sh0[N,3] shN[N,15,3] opacity[N] scale[N,3] rot[N,4] — 59 fp32 = 236 B per splat
  *   (editor.cpp:1578), raw (pre-activation) values; activations as gaussian_model.cpp:137-159.
  *
+ * Alignment: every DEVICE array handed over (dvs_splats, dvs_splat_grads, images) must start on a 16-byte boundary: the kernels move
+ * rot, the tiled shN chunks and the staged 3-float groups as 16-byte vectors. Misaligned pointers are rejected (DVS_ERR_INVALID).
+ *
  * Threading: a dvs_ctx is single-caller (one in-flight view); use one ctx per concurrent view.
  * All work is enqueued on the hipStream_t passed in (as void*). Functions that return counts to
  * the host synchronise that stream once (documented per function).

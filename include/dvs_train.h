@@ -54,7 +54,8 @@ int dvs_adam_step(void* stream, float* param, const float* grad, float* m, float
  *                skipping them is exact (chunks needed for degree d: ceil(3*((d+1)^2-1)/4)).
  *   visible      nullable int32[n_splats] (dvs_fwd_state.radii of this view): when given, only splats with visible[i] > 0 are updated and
  *                the moments of the others do not decay — the reference's `visibleAdam` option (gs_train.cpp:87; the "sparse Adam"
- *                of Taming-3DGS). NULL = dense Adam, identical to dvs_adam_step per group. */
+ *                of Taming-3DGS). NULL = dense Adam, identical to dvs_adam_step per group.
+ *   alignment    param / grad / m / v of every group must be 16-byte aligned (moved as float4); DVS_ERR_INVALID otherwise. */
 typedef struct dvs_adam_group {
     float* param;
     const float* grad;

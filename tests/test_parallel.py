@@ -88,14 +88,22 @@ def test_view_sharding():
 
 def test_grad_buffer_layout():
     from divshot_amd.parallel import GradBuffer, ROW_FLOATS
-    gb = GradBuffer(10, torch.device("cpu"))
-    assert ROW_FLOATS == 59 and gb.flat.numel() == 590          # 59 fp32 = 236 B per splat (editor.cpp:1578)
+    gb = GradBuffer(12, torch.device("cpu"))                     # a multiple of 4 splats: no pad floats
+    assert ROW_FLOATS == 59 and gb.flat.numel() == 12 * 59      # 59 fp32 = 236 B per splat (editor.cpp:1578)
     gb.views["rot"][3, 2] = 7.0
-    assert gb.flat[10 * (3 + 3) + 3 * 4 + 2] == 7.0             # flat order: pos, scale, rot, opacity | sh0, shN
-    assert gb.flat_geom.numel() == 110 and gb.flat_sh.numel() == 480
-    gb.views["shN"][9, 14, 2] = 3.0
+    assert gb.flat[12 * (3 + 3) + 3 * 4 + 2] == 7.0             # flat order: pos, scale, rot, opacity | sh0, shN
+    assert gb.flat_geom.numel() == 12 * 11 and gb.flat_sh.numel() == 12 * 48
+    gb.views["shN"][11, 14, 2] = 3.0
     assert gb.flat[-1] == 3.0
     assert gb.all_reduce() is None                              # no process group: single-GPU path is a no-op
+    # any splat count: every group starts on a 16-byte boundary (the kernels move rot / shN / staged 3-float groups as 16-B vectors)
+    for n in (1, 10, 257):
+        g = GradBuffer(n, torch.device("cpu"))
+        base = g.flat.data_ptr()
+        for k, v in g.views.items():
+            assert (v.data_ptr() - base) % 16 == 0, (n, k)
+            assert v.numel() == n * {"pos": 3, "sh0": 3, "shN": 45, "opacity": 1, "scale": 3, "rot": 4}[k]
+        assert g.flat_geom.numel() + g.flat_sh.numel() == g.flat.numel() and g.flat.numel() < n * 59 + 24
 
 
 def test_two_rank_gradient_allreduce_gloo():
