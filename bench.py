@@ -137,7 +137,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--absgrad", type=int, default=1, help="accumulate |dL/dmean2D| (reference default --absgrad true, main.cpp:44)")
-    ap.add_argument("--contexts", type=int, default=2, help="rasterizer contexts / HIP streams the views of a step are pipelined over")
+    ap.add_argument("--mode", default="batch", choices=["batch", "grouped", "pipelined"],
+                    help="batch (default, the measured winner): the views of a rank go through ONE multi-view pass (dvs_raster_forward_views: "
+                         "parameters read once, one sort / scan / composite launch per step); grouped: --groups passes pipelined over two "
+                         "contexts / streams; pipelined: one view per pass (the round-1 shape)")
+    ap.add_argument("--groups", type=int, default=2, help="grouped mode: multi-view groups per rank and step")
+    ap.add_argument("--contexts", type=int, default=2, help="rasterizer contexts / HIP streams the groups of a step are pipelined over")
     ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
                     help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
                          "12 B per splat per view, SH rows rebuilt locally, gathers overlapped with compute); auto = factorised")
@@ -202,10 +207,17 @@ def main():
     targets = [torch.from_numpy(dv.synth_target(spec, i)).to(dev) for i in my_views]
     cam, target = cams[0], targets[0]
     params = params_to_device(P, dev)
-    # Views of one step are independent, so they are software-pipelined over two rasterizer contexts on two HIP streams:
-    # the HBM/latency-bound front of view v+1 (preprocess, sorts) runs under the VALU-bound composite kernels of view v.
-    n_ctx = max(1, min(args.contexts, VPS))
-    rasts = [Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H) for _ in range(n_ctx)]
+    # The rank's views of a step form K groups; a group goes through the multi-view pass of the C-ABI (dvs_raster_forward_views /
+    # dvs_raster_backward_*: parameters read once, one depth sort / scan / (view, tile) sort / composite launch for the group), and
+    # the groups are software-pipelined over two rasterizer contexts on two HIP streams: the HBM-bound front of group g+1 (A2, sorts)
+    # runs under the VALU-bound composite kernels of group g, the A9 of group g under the composite backward of group g+1.
+    #   --mode batch = 1 group (everything in lockstep) | grouped = --groups K (default 2) | pipelined = one view per group (round 1)
+    K = 1 if args.mode == "batch" else (VPS if args.mode == "pipelined" else max(1, min(args.groups, VPS)))
+    while VPS % K:
+        K -= 1
+    G = VPS // K                                  # views per group
+    n_ctx = max(1, min(args.contexts, K))
+    rasts = [Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H, max_views=G) for _ in range(n_ctx)]
     for r_ in rasts:
         r_.set_backward_variant(args.bwd_variant)
         r_.set_forward_variant(args.fwd_variant)
@@ -220,18 +232,20 @@ def main():
     flat, grads = gbuf.flat, dict(gbuf.views)
     if args.absgrad:
         grads["absgrad2d"] = torch.zeros((n, 2), dtype=torch.float32, device=dev)
-    outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
-    out = outs[0]
+    outs = [torch.empty((G, 3, H, W), dtype=torch.float32, device=dev) for _ in range(n_ctx)]
+    out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     inv_P = 1.0 / (W * H)
-    # upstream gradient dL/drgb = (rgb - target) / P formed by ONE elementwise kernel per view: rgb * (1/P) + (-target / P), the
+    # upstream gradient dL/drgb = (rgb - target) / P formed by ONE elementwise kernel per group: rgb * (1/P) + (-target / P), the
     # second term prepared once (the targets are constant inputs)
     neg_targets_scaled = [(-t_ * inv_P).contiguous() for t_ in targets]
+    neg_targets_group = [torch.stack(neg_targets_scaled[gi * G:(gi + 1) * G]).contiguous() for gi in range(K)]
+    cams_group = [cams[gi * G:(gi + 1) * G] for gi in range(K)]
 
     exchange = args.exchange
     if exchange == "auto":
         # exposed bytes received per splat per rank: ring all-reduce of B bytes ~ 2 (w-1)/w B; all-gather of b bytes ~ (w-1) b.
-        # The factorised exchange gathers views 0..VPS-2 under the compute of the following view, so only one gather is exposed:
-        # (w-1) 12 + ring 44 < ring 236 for every world size.
+        # The factorised exchange gathers the views of all but the last group under the compute of the following group:
+        # (w-1) 12 G + ring 44 < ring 236 for every world size.
         exchange = "factorised"
     factorised = dist is not None and exchange == "factorised"
     if factorised:
@@ -248,30 +262,31 @@ def main():
 
     def step(timed=False):
         step_done.record(main_stream)              # everything enqueued so far (previous step incl. its exchange)
-        for v in range(VPS):
-            c = v % n_ctx
+        for gi in range(K):
+            c = gi % n_ctx
             st = streams[c]
             with torch.cuda.stream(st):
-                if n_ctx > 1 and v < n_ctx:
+                if n_ctx > 1 and gi < n_ctx:
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
-                img = rasts[c].forward(params, cams[v], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled,
-                                       grad_mode=args.grad_mode)
-                dL = torch.add(neg_targets_scaled[v], img, alpha=inv_P)
+                imgs = rasts[c].forward_views(params, cams_group[gi], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled,
+                                              grad_mode=args.grad_mode)
+                dL = torch.add(neg_targets_group[gi], imgs, alpha=inv_P)
                 g = grads
                 if factorised:
-                    g = dict(grads); g["dcolor"] = fx.dcolor_local[v]
+                    g = dict(grads); g["dcolor"] = fx.dcolor_local[gi * G:(gi + 1) * G]
                 # A8 (composite backward) writes only this context's intermediate rows: it needs no ordering against the other
-                # view. Only A9, which accumulates into the shared gradient rows non-atomically, runs in view order.
+                # group. Only A9, which accumulates into the shared gradient rows non-atomically, runs in group order.
                 rasts[c].backward_composite(dL)
-                if n_ctx > 1 and v > 0:
-                    st.wait_event(bwd_done[(v - 1) % n_ctx])
-                rasts[c].backward_project(grads=g, accumulate=(v > 0), factorised_sh=factorised)
+                if n_ctx > 1 and gi > 0:
+                    st.wait_event(bwd_done[(gi - 1) % n_ctx])
+                rasts[c].backward_project(grads=g, accumulate=(gi > 0), factorised_sh=factorised)
                 if n_ctx > 1:
                     bwd_done[c].record(st)
-                if factorised and v < VPS - 1:
-                    fx.gather_view(v, bwd_done[c] if n_ctx > 1 else None)      # overlaps with the next view's kernels
+                if factorised and gi < K - 1:
+                    for v in range(gi * G, (gi + 1) * G):
+                        fx.gather_view(v, bwd_done[c] if n_ctx > 1 else None)      # overlaps with the next group's kernels
         if n_ctx > 1:
-            main_stream.wait_event(bwd_done[(VPS - 1) % n_ctx])
+            main_stream.wait_event(bwd_done[(K - 1) % n_ctx])
         if dist is not None:
             ea = None
             if timed:
@@ -309,8 +324,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    for r_ in rasts:
+        r_.get_num_rendered()         # raises if an asynchronous forward of the timed region overflowed its instance arena
     grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
                                                                                    # (taken before the profiling iterations reuse the buffer)
+    # everything below measures ONE view at a time: its own single-view context (the step's contexts are sized and primed for groups)
+    rast1 = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
+    rast1.set_backward_variant(args.bwd_variant); rast1.set_forward_variant(args.fwd_variant); rast1.set_async(bool(args.async_forward))
+    if rank == 0:
+        rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode)
     # ---- strict single-view figure of SURVEY.md §8(d): 1 / (t_fwd + t_bwd), one view at a time on one stream, no pipelining ----
     strict = None
     if rank == 0 and args.profile_iters > 0:
@@ -320,9 +342,9 @@ def main():
         for it_ in range(n_strict + 5):
             if it_ == 5:
                 ev0.record(main_stream)
-            img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode)
+            img = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode)
             dL = torch.add(neg_targets_scaled[0], img, alpha=inv_P)
-            rast.backward(dL, grads=g_strict)
+            rast1.backward(dL, grads=g_strict)
         ev1.record(main_stream)
         torch.cuda.synchronize()
         ms_view = ev0.elapsed_time(ev1) / n_strict
@@ -350,23 +372,23 @@ def main():
     # ---- per-stage hipEvent timing (separate iterations; timing mode synchronises per call) --------------
     stage_ms = {}
     if rank == 0 and args.profile_iters > 0:
-        rast.enable_timing(True)
+        rast1.enable_timing(True)
         acc = {}
         for _ in range(args.profile_iters):
-            img = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
+            img = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
             dL = (img - target) * inv_P
-            rast.backward(dL, grads={k: v for k, v in grads.items() if k != "dcolor"})
-            for k, v in rast.stage_timing().items():
+            rast1.backward(dL, grads={k: v for k, v in grads.items() if k != "dcolor"})
+            for k, v in rast1.stage_timing().items():
                 acc.setdefault(k, []).append(v)
-        rast.enable_timing(False)
+        rast1.enable_timing(False)
         stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     if dist is not None:
         dist.barrier()
 
     if rank == 0:
-        st = rast.state
-        V = int((torch.from_numpy(rast._d2h(st.radii, (n,), np.int32)) > 0).sum())
-        T = int(rast.get_num_rendered())          # (synchronises; also raises on an instance-arena overflow during the run)
+        st = rast1.state
+        V = int((torch.from_numpy(rast1._d2h(st.radii, (n,), np.int32)) > 0).sum())
+        T = int(rast1.get_num_rendered())          # (synchronises; also raises on an instance-arena overflow during the run)
         Ppix = W * H
         tiles = st.tiles_x * st.tiles_y
         ab, p = algorithmic_bytes(n, V, T, Ppix, tiles, deg, bool(args.absgrad))
@@ -395,7 +417,8 @@ def main():
             dom = max(single, key=single.get)
             in_step_ms = probe.get(dom)                       # mean launch duration inside the pipelined step (kernel probe)
             dur_ms = in_step_ms if in_step_ms else single[dom]
-            achieved = ab[dom] / (dur_ms * 1e-3) / 1e9
+            views_per_launch = G if in_step_ms else 1          # a launch inside the step composites all views of its group
+            achieved = ab[dom] * views_per_launch / (dur_ms * 1e-3) / 1e9
             traffic, traffic_src = None, None
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob
@@ -432,7 +455,7 @@ def main():
                 pass
             roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dur_ms,
+                        "algorithmic_bytes_per_launch": ab[dom] * views_per_launch, "views_per_launch": views_per_launch, "avg_launch_ms": dur_ms,
                         "avg_launch_ms_isolated": single[dom], "avg_launch_source": ("hipEvent pairs around the kernel inside a replica of the timed "
                         "region (dvs_enable_kernel_probe)" if in_step_ms else "per-stage hipEvent timing, one view at a time"), "valu_issue": valu,
                         "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r*_pmc_sq.txt), "
@@ -457,9 +480,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} splats, {W}x{H}, SH degree {deg}, {GLOBAL_VIEWS} views per iteration "
                                    + ("(weak scaling: fixed per GPU), " if weak else f"sharded over {world} GPU(s) (BASELINE config C4), ") + f"{VPS} view(s) per GPU per step"
-                                   + (" software-pipelined over two contexts/streams, gradients accumulated" if VPS > 1 else "")
+                                   + (f" as {K} multi-view pass(es) of {G} view(s) (dvs_raster_forward_views / dvs_raster_backward_*)"
+                                      + (" software-pipelined over two contexts/streams, gradients accumulated" if K > 1 else ""))
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "async_forward": bool(args.async_forward), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "groups": K, "views_per_group": G, "async_forward": bool(args.async_forward), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,
@@ -471,7 +495,7 @@ def main():
         # compute-side figure of SURVEY.md §8(d): pixel-splat interactions I = sum over tiles of (list entries walked before all 256
         # pixels of the tile terminate) x 256, from the saved n_contrib of the last profiled view
         try:
-            nc = torch.from_numpy(rast._d2h(st.n_contrib, (H, W), np.uint32).astype(np.int64))
+            nc = torch.from_numpy(rast1._d2h(st.n_contrib, (H, W), np.uint32).astype(np.int64))
             ty_, tx_ = st.tiles_y, st.tiles_x
             pad = torch.zeros((ty_ * 16, tx_ * 16), dtype=torch.int64); pad[:H, :W] = nc
             per_tile = pad.view(ty_, 16, tx_, 16).permute(0, 2, 1, 3).reshape(ty_ * tx_, 256).max(dim=1).values
@@ -491,13 +515,13 @@ def main():
             ref = cpu_baseline.reference
             if ref is not None:
                 try:
-                    img_g = rast.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
-                    g1 = rast.backward(((img_g - target) * inv_P).contiguous())
+                    img_g = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
+                    g1 = rast1.backward(((img_g - target) * inv_P).contiguous())
                     torch.cuda.synchronize()
                     ok = ~ref["fragile"]
                     ih = img_g.cpu().numpy()
                     err = np.abs(ih[:, ok] - ref["img"][:, ok]) / (1e-4 * np.abs(ref["img"][:, ok]) + 1e-6)
-                    par = {"view": 0, "num_rendered_equal": int(rast.get_num_rendered()) == ref["num_rendered"],
+                    par = {"view": 0, "num_rendered_equal": int(rast1.get_num_rendered()) == ref["num_rendered"],
                            "rgb_max_err_over_tol(1e-4 rel + 1e-6)": float(err.max()), "fragile_pixels": int(ref["fragile"].sum())}
                     for k_ in ("pos", "sh0", "opacity", "scale", "rot"):
                         a, b = g1[k_].double().cpu().numpy(), np.asarray(ref["grads"][k_], np.float64)
@@ -506,6 +530,7 @@ def main():
                 except Exception as e:      # noqa: BLE001
                     rec["parity_vs_oracle"] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)
+    rast1.close()
     for r_ in rasts:
         r_.close()
     if dist is not None:

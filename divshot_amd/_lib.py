@@ -68,13 +68,18 @@ class SceneSpec(C.Structure):
 # every symbol include/*.h declares (tests/test_abi.py checks this list against the headers)
 _PROTOS = {
     "dvs_create": (C.c_void_p, [C.c_int, C.c_size_t, C.c_int, C.c_int]),
+    "dvs_create_views": (C.c_void_p, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "dvs_destroy": (None, [C.c_void_p]),
+    "dvs_raster_forward_views": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.c_int, C.POINTER(Opts), C.c_void_p]),
+    "dvs_raster_backward_views": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.c_int, C.POINTER(Opts),
+                                            C.c_void_p, C.POINTER(SplatGrads)]),
+    "dvs_get_view_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(FwdState)]),
     "dvs_raster_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
                                      C.c_void_p, C.POINTER(FwdState), C.POINTER(C.c_uint64)]),
     "dvs_raster_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
                                       C.c_void_p, C.POINTER(SplatGrads)]),
-    "dvs_raster_backward_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.POINTER(Opts), C.c_void_p]),
-    "dvs_raster_backward_project": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.POINTER(Opts),
+    "dvs_raster_backward_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Opts), C.c_void_p]),
+    "dvs_raster_backward_project": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.c_void_p, C.POINTER(Opts),
                                               C.POINTER(SplatGrads)]),
     "dvs_sh_grad_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]),

@@ -292,12 +292,16 @@ hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_id
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rect_sorted,
             const uint32_t* __restrict__ block_offsets, int tiles_x, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat,
-            uint64_t capacity) {
+            uint64_t capacity, int n_per_view, int n_views, int tiles_per_view) {
     __shared__ uint32_t tmp[SORT_WAVES + 1];
     const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
     uint32_t id = 0, touched = 0;
     uint2 r = make_uint2(0u, 0u);
     if (j < n) { id = sorted_ids[j]; r = rect_sorted[j]; touched = rect_tiles(r); }
+    // multi-view batch: the sort value is the global index view * n_per_view + splat; the tile ids of view v start at v * tiles_per_view
+    uint32_t view = 0;
+    for (int k = 1; k < n_views; ++k) view += (id >= (uint32_t)k * (uint32_t)n_per_view) ? 1u : 0u;
+    const uint32_t tile0 = view * (uint32_t)tiles_per_view;
     uint32_t tot;
     uint32_t off = block_excl_scan(touched, tmp, &tot) + block_offsets[blockIdx.x];
     const int minx = (int)(r.x & 0xFFFFu), miny = (int)(r.y & 0xFFFFu), maxx = (int)(r.x >> 16), maxy = (int)(r.y >> 16);
@@ -307,7 +311,7 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restr
         for (int y = miny; y < maxy; ++y)
             for (int x = minx; x < maxx; ++x) {
                 if (off < capacity) {
-                    inst_tile[off] = (uint32_t)(y * tiles_x + x);
+                    inst_tile[off] = tile0 + (uint32_t)(y * tiles_x + x);
                     inst_splat[off] = id;
                 }
                 ++off;
@@ -321,10 +325,11 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restr
         big &= big - 1;
         const uint32_t b_id = __shfl(id, src, 64), b_touched = __shfl(touched, src, 64), b_off = __shfl(off, src, 64);
         const int b_minx = __shfl(minx, src, 64), b_miny = __shfl(miny, src, 64), b_w = __shfl(w, src, 64);
+        const uint32_t b_tile0 = __shfl(tile0, src, 64);
         for (uint32_t k = lane; k < b_touched; k += 64) {
             const int y = b_miny + (int)(k / (uint32_t)b_w), x = b_minx + (int)(k % (uint32_t)b_w);
             if ((uint64_t)b_off + k < capacity) {
-                inst_tile[b_off + k] = (uint32_t)(y * tiles_x + x);
+                inst_tile[b_off + k] = b_tile0 + (uint32_t)(y * tiles_x + x);
                 inst_splat[b_off + k] = b_id;
             }
         }
@@ -332,11 +337,12 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restr
 }
 
 hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
-                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity) {
+                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity,
+                                int n_per_view, int n_views, int tiles_per_view) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
     if (nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect_sorted, block_offsets,
-                       tiles_x, inst_tile, inst_splat, capacity);
+                       tiles_x, inst_tile, inst_splat, capacity, n_per_view, n_views, tiles_per_view);
     return hipGetLastError();
 }
 

@@ -68,11 +68,14 @@ struct dvs_ctx {
     int device = 0;
     size_t max_splats = 0;
     int max_w = 0, max_h = 0;
+    int max_views = 1;                   // views one forward can batch (dvs_create_views)
+    int n_views = 1;                     // views of the last forward
     Buf radii, splat2d, depth, flags, tiles_touched, rect, rect_sorted, key[2], ids[2], scan_blocks;
     Buf inst_tile[2], inst_splat[2];
     Buf sort_scratch, tmp_keys, tmp_vals;
     Buf ranges, final_T, n_contrib;
     Buf g_rows;
+    Buf dcolor;                          // [views, n, 3] per-view colour gradients of a batched A9 when the caller gives no buffer
     uint64_t* total_dev = nullptr;       // [0] = T of the last forward, [1] = number of forwards whose T exceeded the instance capacity
     uint64_t* total_host = nullptr;      // pinned copy of both words (async: refreshed by every forward, read by the next one)
     uint64_t inst_cap = 0;               // instances the instance arenas can hold
@@ -142,9 +145,9 @@ int ensure_splat_arenas(dvs_ctx* c, size_t n) {
 #undef ENS
     return DVS_OK;
 }
-int ensure_image_arenas(dvs_ctx* c, int w, int h) {
-    const size_t P = (size_t)w * h;
-    const size_t tiles = (size_t)((w + DVS_TILE - 1) / DVS_TILE) * ((h + DVS_TILE - 1) / DVS_TILE);
+int ensure_image_arenas(dvs_ctx* c, int w, int h, int views) {
+    const size_t P = (size_t)w * h * views;
+    const size_t tiles = (size_t)((w + DVS_TILE - 1) / DVS_TILE) * ((h + DVS_TILE - 1) / DVS_TILE) * views;
     int r;
     if ((r = c->ranges.ensure(tiles * 8)) != DVS_OK) return r;
     if ((r = c->final_T.ensure(P * 4)) != DVS_OK) return r;
@@ -174,16 +177,17 @@ extern "C" {
 const char* dvs_last_error(void) { return g_last_error.c_str(); }
 const char* dvs_version(void) { return "divshot_amd raster 0.1 (gfx950)"; }
 
-dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
+dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, int max_views) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || device < 0 || device >= count) {
         g_last_error = "dvs_create: no such HIP device (the rasterizer has no CPU fallback)";
         return nullptr;
     }
+    if (max_views < 1 || max_views > DVS_MAX_VIEWS) { g_last_error = "dvs_create_views: max_views must be in [1, 16]"; return nullptr; }
     if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e, __FILE__, __LINE__); return nullptr; }
     dvs_ctx* c = new dvs_ctx();
-    c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h;
+    c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h; c->max_views = max_views;
     if (const char* v = getenv("DVS_BWD_VARIANT")) c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_REDUCE;
     if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
     if (hipMalloc((void**)&c->total_dev, 16) != hipSuccess || hipHostMalloc((void**)&c->total_host, 16, hipHostMallocDefault) != hipSuccess ||
@@ -194,20 +198,21 @@ dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) {
     }
     c->total_host[0] = c->total_host[1] = 0;
     if (const char* v = getenv("DVS_ASYNC")) c->async_T = v[0] == '1';
-    if (ensure_splat_arenas(c, max_splats) != DVS_OK || ensure_image_arenas(c, max_w, max_h) != DVS_OK ||
-        ensure_instance_arenas(c, (uint64_t)max_splats * 4) != DVS_OK) {
+    if (ensure_splat_arenas(c, max_splats * (size_t)max_views) != DVS_OK || ensure_image_arenas(c, max_w, max_h, max_views) != DVS_OK ||
+        ensure_instance_arenas(c, (uint64_t)max_splats * 4 * (uint64_t)max_views) != DVS_OK) {
         dvs_destroy(c);
         return nullptr;
     }
     return c;
 }
+dvs_ctx* dvs_create(int device, size_t max_splats, int max_w, int max_h) { return dvs_create_views(device, max_splats, max_w, max_h, 1); }
 
 void dvs_destroy(dvs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     Buf* all[] = {&c->radii, &c->splat2d, &c->depth, &c->flags, &c->tiles_touched, &c->rect, &c->rect_sorted, &c->key[0], &c->key[1],
                   &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
-                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows};
+                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows, &c->dcolor};
     for (Buf* b : all) b->release();
     if (c->total_dev) (void)hipFree(c->total_dev);
     if (c->total_host) (void)hipHostFree(c->total_host);
@@ -216,42 +221,36 @@ void dvs_destroy(dvs_ctx* c) {
     delete c;
 }
 
-int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
-                       float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered) {
-    if (!c || !p || !cam || !opts || !out_rgb) { g_last_error = "dvs_raster_forward: null argument"; return DVS_ERR_INVALID; }
-    if (p->n < 0 || cam->width <= 0 || cam->height <= 0 || opts->sh_degree < 0 || opts->sh_degree > 3 ||
-        (opts->shn_layout != DVS_SHN_ROWS && opts->shn_layout != DVS_SHN_TILED)) {
-        g_last_error = "dvs_raster_forward: bad n / image size / sh_degree"; return DVS_ERR_INVALID;
-    }
-    if (p->n > 0 && (((uintptr_t)p->pos | (uintptr_t)p->sh0 | (uintptr_t)p->shN | (uintptr_t)p->opacity | (uintptr_t)p->scale | (uintptr_t)p->rot) & 15u)) {
-        g_last_error = "dvs_raster_forward: parameter arrays must be 16-byte aligned"; return DVS_ERR_INVALID;
-    }
-    if ((size_t)p->n > c->max_splats || cam->width > c->max_w || cam->height > c->max_h) {
-        g_last_error = "dvs_raster_forward: exceeds the capacity given to dvs_create"; return DVS_ERR_CAPACITY;
-    }
-    HIPCHECK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+// A2..A7 for the n_views views of a batch (n_views = 1: the single-view API). Per-splat arrays are view-major [view][splat]; the
+// sort value of an element is its global index view * n + splat; tile ids are view * tiles + tile: ONE depth sort, ONE scan, ONE
+// duplication, ONE tile sort and ONE composite launch cover the whole iteration.
+static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dvs_camera* cams, int V, const dvs_opts* opts,
+                         float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered) {
+    const dvs_camera* cam = &cams[0];
     const int n = p->n, W = cam->width, H = cam->height;
     const int tiles_x = (W + DVS_TILE - 1) / DVS_TILE, tiles_y = (H + DVS_TILE - 1) / DVS_TILE, tiles = tiles_x * tiles_y;
-    const DvsCam dcam = to_dev_cam(*cam);
+    const size_t nV = (size_t)n * V;
+    DvsCams dcams;
+    float bgs[DVS_MAX_VIEWS * 3];
+    for (int v = 0; v < V; ++v) { dcams.c[v] = to_dev_cam(cams[v]); for (int k = 0; k < 3; ++k) bgs[3 * v + k] = cams[v].bg[k]; }
     c->have_fwd = false;
     c->rows_pending = false;
     timing_reset(c);
     StageTimer tm(c, st);
 
-    // A2 preprocess
+    // A2 preprocess: one lane per splat, all views
     size_t e0 = tm.mark();
-    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree,
+    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
                                        opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
                                        c->depth.as<float>(),
                                        c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
                                        c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>()));
     size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
-    // A5 (low 32 key bits): depth sort over splats, 4 x 8-bit LSD passes
+    // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
     int cur = 0;
     for (int pass = 0; pass < 4; ++pass) {
         HIPCHECK(dvs_launch_sort_pass(st, c->key[cur].as<uint32_t>(), c->ids[cur].as<uint32_t>(), c->key[cur ^ 1].as<uint32_t>(),
-                                      c->ids[cur ^ 1].as<uint32_t>(), (uint64_t)n, pass * 8, 8, c->sort_scratch.as<uint32_t>()));
+                                      c->ids[cur ^ 1].as<uint32_t>(), (uint64_t)nV, pass * 8, 8, c->sort_scratch.as<uint32_t>()));
         cur ^= 1;
     }
     size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
@@ -281,7 +280,7 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
         T_dev = c->total_dev;
         T_expected = lastT > 0 ? lastT + lastT / 16 + 4096 : 0;      // grid size only: the kernels stride over whatever T turns out to be
     }
-    HIPCHECK(dvs_launch_tile_scan(st, n, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
+    HIPCHECK(dvs_launch_tile_scan(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
                                   c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull));
     HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 16, hipMemcpyDeviceToHost, st));
     size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
@@ -294,12 +293,12 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
 
     // A4 duplicate
     size_t e4 = tm.mark();
-    HIPCHECK(dvs_launch_duplicate(st, n, c->ids[cur].as<uint32_t>(), c->rect_sorted.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
-                                  tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap));
+    HIPCHECK(dvs_launch_duplicate(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect_sorted.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
+                                  tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap, n, V, tiles));
     size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
-    // A5 (high key bits): tile-id sort over instances
+    // A5 (high key bits): sort by (view, tile) over the instances
     int icur = 0;
-    const int tile_bits = bits_for((uint32_t)(tiles - 1));
+    const int tile_bits = bits_for((uint32_t)(tiles * V - 1));
     for (int shift = 0; shift < tile_bits; shift += 8) {
         HIPCHECK(dvs_launch_sort_pass(st, c->inst_tile[icur].as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                       c->inst_tile[icur ^ 1].as<uint32_t>(), c->inst_splat[icur ^ 1].as<uint32_t>(), T, shift,
@@ -308,14 +307,13 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     }
     size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
     // A6 ranges
-    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles, T_dev, T_expected));
+    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles * V, T_dev, T_expected));
     size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     // A7 composite
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
-    if (c->fwd_variant == DVS_FWD_QUADRANT)
-        HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
-                                       c->splat2d.as<float>(), cam->bg, out_rgb,
-                                       c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
+    if (c->fwd_variant == DVS_FWD_QUADRANT || V > 1)
+        HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+                                       c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
     else
         HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                               c->splat2d.as<float>(), cam->bg, out_rgb,
@@ -329,7 +327,9 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     s.tiles_touched = c->tiles_touched.as<uint32_t>();
     s.sorted_tile = c->inst_tile[icur].as<uint32_t>(); s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
     s.ranges = c->ranges.as<uint32_t>(); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
-    s.num_rendered = c->async_T ? DVS_T_UNKNOWN : T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y; s._pad = 0;
+    s.num_rendered = c->async_T ? DVS_T_UNKNOWN : T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y;
+    s._pad = 0;
+    c->n_views = V;
     c->have_fwd = true;
     if (saved) *saved = s;
     if (num_rendered) *num_rendered = c->async_T ? DVS_T_UNKNOWN : T;
@@ -337,47 +337,118 @@ int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_
     return DVS_OK;
 }
 
-// A8: zero the 48-B rows if needed, then the alpha-composite backward into them
-static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb, StageTimer* tm) {
+static int check_fwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cams, int V, const dvs_opts* opts, const float* out_rgb) {
+    if (!c || !p || !cams || !opts || !out_rgb) { g_last_error = "dvs_raster_forward: null argument"; return DVS_ERR_INVALID; }
+    if (V < 1 || V > c->max_views) { g_last_error = "dvs_raster_forward: n_views exceeds the max_views given to dvs_create_views"; return DVS_ERR_CAPACITY; }
+    const dvs_camera* cam = &cams[0];
+    if (p->n < 0 || cam->width <= 0 || cam->height <= 0 || opts->sh_degree < 0 || opts->sh_degree > 3 ||
+        (opts->shn_layout != DVS_SHN_ROWS && opts->shn_layout != DVS_SHN_TILED)) {
+        g_last_error = "dvs_raster_forward: bad n / image size / sh_degree"; return DVS_ERR_INVALID;
+    }
+    for (int v = 1; v < V; ++v)
+        if (cams[v].width != cam->width || cams[v].height != cam->height) { g_last_error = "dvs_raster_forward: the views of a batch must share one image size"; return DVS_ERR_INVALID; }
+    if (p->n > 0 && (((uintptr_t)p->pos | (uintptr_t)p->sh0 | (uintptr_t)p->shN | (uintptr_t)p->opacity | (uintptr_t)p->scale | (uintptr_t)p->rot) & 15u)) {
+        g_last_error = "dvs_raster_forward: parameter arrays must be 16-byte aligned"; return DVS_ERR_INVALID;
+    }
+    if ((size_t)p->n > c->max_splats || cam->width > c->max_w || cam->height > c->max_h) {
+        g_last_error = "dvs_raster_forward: exceeds the capacity given to dvs_create"; return DVS_ERR_CAPACITY;
+    }
+    if ((uint64_t)p->n * (uint64_t)V >= (1ull << 32)) { g_last_error = "dvs_raster_forward: n * n_views must stay below 2^32"; return DVS_ERR_CAPACITY; }
+    return DVS_OK;
+}
+
+int dvs_raster_forward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                       float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered) {
+    int r = check_fwd_args(c, p, cam, 1, opts, out_rgb);
+    if (r != DVS_OK) return r;
+    HIPCHECK(hipSetDevice(c->device));
+    return forward_views(c, (hipStream_t)stream, p, cam, 1, opts, out_rgb, saved, num_rendered);
+}
+
+int dvs_raster_forward_views(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cams, int n_views, const dvs_opts* opts,
+                             float* out_rgb) {
+    int r = check_fwd_args(c, p, cams, n_views, opts, out_rgb);
+    if (r != DVS_OK) return r;
+    HIPCHECK(hipSetDevice(c->device));
+    return forward_views(c, (hipStream_t)stream, p, cams, n_views, opts, out_rgb, nullptr, nullptr);
+}
+
+int dvs_get_view_state(dvs_ctx* c, int view, dvs_fwd_state* out) {
+    if (!c || !out) { g_last_error = "dvs_get_view_state: null argument"; return DVS_ERR_INVALID; }
+    if (!c->have_fwd || view < 0 || view >= c->n_views) { g_last_error = "dvs_get_view_state: no such view in the last forward"; return DVS_ERR_STATE; }
+    dvs_fwd_state s = c->st;
+    const size_t on = (size_t)view * s.n, op = (size_t)view * s.width * s.height, ot = (size_t)view * s.tiles_x * s.tiles_y;
+    s.radii += on; s.splat2d += on * DVS_S2D_FLOATS; s.depth += on; s.flags += on; s.tiles_touched += on;
+    s.ranges += 2 * ot; s.final_T += op; s.n_contrib += op;
+    *out = s;              // sorted_tile / sorted_splat stay the batch-wide lists: ranges index into them, values are view * n + splat
+    return DVS_OK;
+}
+
+// A8: zero the 48-B rows if needed, then the alpha-composite backward into them (all views of the last forward in one launch)
+static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, const dvs_opts* opts, const float* dL_drgb, StageTimer* tm) {
     const dvs_fwd_state& s = c->st;
+    const int V = c->n_views;
     size_t e0 = tm ? tm->mark() : 0;
     if (!c->rows_clean) HIPCHECK(hipMemsetAsync(c->g_rows.p, 0, c->g_rows.bytes, st));
     c->rows_clean = false;
     size_t e1 = tm ? tm->mark() : 0;
     if (tm) tm->span("bwd_zero", e0, e1);
+    float bgs[DVS_MAX_VIEWS * 3];
+    for (int v = 0; v < V; ++v) for (int k = 0; k < 3; ++k) bgs[3 * v + k] = cams[v].bg[k];
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
-    if (c->bwd_variant == DVS_BWD_BLOCKS)
+    if (c->bwd_variant == DVS_BWD_BLOCKS && V == 1)
         HIPCHECK(dvs_launch_render_bwd_blocks(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
-                                              cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
+                                              cams[0].bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
     else
-        HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, s.ranges, s.sorted_splat, s.splat2d,
-                                       cam->bg, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
-                                       c->bwd_variant));
+        HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d,
+                                       bgs, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
+                                       V > 1 ? DVS_BWD_REDUCE : c->bwd_variant));
     if (c->probe) (void)probe_event(c, st);
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
     return DVS_OK;
 }
-// A9: rows -> parameter gradients (re-zeroes the rows it reads)
-static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+// A9: rows -> parameter gradients (re-zeroes the rows it reads). A multi-view batch in the tiled layout goes through ONE pass that
+// reads the parameters once and writes the geometry gradients once (+ the per-view colour gradients), the SH rows are then built from
+// those; otherwise (one view, or the reference's row layout) the per-view kernel runs once per view, accumulating.
+static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dvs_camera* cams, const dvs_opts* opts,
                        const dvs_splat_grads* out, StageTimer* tm) {
     const dvs_fwd_state& s = c->st;
-    const DvsCam dcam = to_dev_cam(*cam);
+    const int V = c->n_views, n = p->n;
     size_t e2 = tm ? tm->mark() : 0;
-    HIPCHECK(dvs_launch_preprocess_bwd(st, p->n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
-                                       s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->sh0, out->shN, out->opacity,
-                                       out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor,
-                                       opts->accumulate, c->keep_rows ? 0 : 1, opts->shn_layout, opts->grad_mode));
+    if (V > 1 && opts->shn_layout == DVS_SHN_TILED) {
+        DvsCams dcams;
+        float campos[DVS_MAX_VIEWS * 3];
+        for (int v = 0; v < V; ++v) { dcams.c[v] = to_dev_cam(cams[v]); for (int k = 0; k < 3; ++k) campos[3 * v + k] = cams[v].campos[k]; }
+        float* dcol = out->dcolor;
+        if (!dcol) { int r = c->dcolor.ensure((size_t)V * n * 3 * sizeof(float)); if (r != DVS_OK) return r; dcol = c->dcolor.as<float>(); }
+        HIPCHECK(dvs_launch_preprocess_bwd_views(st, n, V, p->pos, p->shN, p->opacity, p->scale, p->rot, dcams, opts->sh_degree,
+                                                 opts->antialias, s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->opacity, out->scale,
+                                                 out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, dcol, opts->accumulate,
+                                                 c->keep_rows ? 0 : 1, opts->grad_mode));
+        if (out->sh0 && out->shN)          // (NULL: the factorised exchange builds them after its all-gather of dcolor)
+            HIPCHECK(dvs_launch_sh_grad_combine(st, n, p->pos, opts->sh_degree, V, campos, dcol, out->sh0, out->shN, opts->accumulate, 1));
+    } else {
+        for (int v = 0; v < V; ++v) {
+            const DvsCam dcam = to_dev_cam(cams[v]);
+            const size_t on = (size_t)v * n;
+            HIPCHECK(dvs_launch_preprocess_bwd(st, n, p->pos, p->shN, p->opacity, p->scale, p->rot, dcam, opts->sh_degree, opts->antialias,
+                                               s.radii + on, s.flags + on, c->g_rows.as<float>() + on * 12, out->pos, out->sh0, out->shN,
+                                               out->opacity, out->scale, out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d,
+                                               out->dcolor ? out->dcolor + on * 3 : nullptr, (opts->accumulate || v > 0) ? 1 : 0,
+                                               c->keep_rows ? 0 : 1, opts->shn_layout, opts->grad_mode));
+        }
+    }
     c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
     c->rows_pending = false;
     if (tm) { size_t e3 = tm->mark(); tm->span("preprocess_bwd", e2, e3); }
     return DVS_OK;
 }
-static int check_bwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts, const char* who) {
+static int check_bwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cams, int V, const dvs_opts* opts, const char* who) {
     static thread_local std::string msg;
-    if (!c || !cam || !opts) { msg = std::string(who) + ": null argument"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
+    if (!c || !cams || !opts) { msg = std::string(who) + ": null argument"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
     if (opts->grad_mode != DVS_GRAD_TRUE && opts->grad_mode != DVS_GRAD_LINEAGE) { msg = std::string(who) + ": bad grad_mode"; g_last_error = msg.c_str(); return DVS_ERR_INVALID; }
-    if (!c->have_fwd || (p && c->st.n != p->n) || c->st.width != cam->width || c->st.height != cam->height) {
+    if (!c->have_fwd || V != c->n_views || (p && c->st.n != p->n) || c->st.width != cams[0].width || c->st.height != cams[0].height) {
         msg = std::string(who) + ": no matching forward on this context"; g_last_error = msg.c_str(); return DVS_ERR_STATE;
     }
     return DVS_OK;
@@ -396,26 +467,35 @@ static int check_grads(const dvs_splats* p, const dvs_splat_grads* out, const ch
     return DVS_OK;
 }
 
-int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
-                        const float* dL_drgb, const dvs_splat_grads* out) {
+static int backward_views(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cams, int V, const dvs_opts* opts,
+                          const float* dL_drgb, const dvs_splat_grads* out, const char* who) {
     int r;
     if (!dL_drgb) { g_last_error = "dvs_raster_backward: null argument"; return DVS_ERR_INVALID; }
-    if ((r = check_grads(p, out, "dvs_raster_backward")) != DVS_OK) return r;
-    if ((r = check_bwd_args(c, p, cam, opts, "dvs_raster_backward")) != DVS_OK) return r;
+    if ((r = check_grads(p, out, who)) != DVS_OK) return r;
+    if ((r = check_bwd_args(c, p, cams, V, opts, who)) != DVS_OK) return r;
     HIPCHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     timing_reset(c);
     StageTimer tm(c, st);
-    if ((r = bwd_composite(c, st, cam, opts, dL_drgb, &tm)) != DVS_OK) return r;
-    if ((r = bwd_project(c, st, p, cam, opts, out, &tm)) != DVS_OK) return r;
+    if ((r = bwd_composite(c, st, cams, opts, dL_drgb, &tm)) != DVS_OK) return r;
+    if ((r = bwd_project(c, st, p, cams, opts, out, &tm)) != DVS_OK) return r;
     if (c->timing) { HIPCHECK(hipStreamSynchronize(st)); timing_collect(c, true); }
     return DVS_OK;
+}
+int dvs_raster_backward(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                        const float* dL_drgb, const dvs_splat_grads* out) {
+    return backward_views(c, stream, p, cam, 1, opts, dL_drgb, out, "dvs_raster_backward");
+}
+int dvs_raster_backward_views(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cams, int n_views, const dvs_opts* opts,
+                              const float* dL_drgb, const dvs_splat_grads* out) {
+    return backward_views(c, stream, p, cams, n_views, opts, dL_drgb, out, "dvs_raster_backward_views");
 }
 
 int dvs_raster_backward_composite(dvs_ctx* c, void* stream, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb) {
     int r;
     if (!dL_drgb) { g_last_error = "dvs_raster_backward_composite: null argument"; return DVS_ERR_INVALID; }
-    if ((r = check_bwd_args(c, nullptr, cam, opts, "dvs_raster_backward_composite")) != DVS_OK) return r;
+    if (!c) { g_last_error = "dvs_raster_backward_composite: null argument"; return DVS_ERR_INVALID; }
+    if ((r = check_bwd_args(c, nullptr, cam, c->n_views, opts, "dvs_raster_backward_composite")) != DVS_OK) return r;
     HIPCHECK(hipSetDevice(c->device));
     return bwd_composite(c, (hipStream_t)stream, cam, opts, dL_drgb, nullptr);
 }
@@ -424,7 +504,8 @@ int dvs_raster_backward_project(dvs_ctx* c, void* stream, const dvs_splats* p, c
                                 const dvs_splat_grads* out) {
     int r;
     if ((r = check_grads(p, out, "dvs_raster_backward_project")) != DVS_OK) return r;
-    if ((r = check_bwd_args(c, p, cam, opts, "dvs_raster_backward_project")) != DVS_OK) return r;
+    if (!c) { g_last_error = "dvs_raster_backward_project: null argument"; return DVS_ERR_INVALID; }
+    if ((r = check_bwd_args(c, p, cam, c->n_views, opts, "dvs_raster_backward_project")) != DVS_OK) return r;
     if (!c->rows_pending) { g_last_error = "dvs_raster_backward_project: no dvs_raster_backward_composite on this context"; return DVS_ERR_STATE; }
     HIPCHECK(hipSetDevice(c->device));
     return bwd_project(c, (hipStream_t)stream, p, cam, opts, out, nullptr);

@@ -48,6 +48,21 @@ struct DvsCam {
     float bg[3];
 };
 
+// The cameras of one multi-view batch (one training iteration renders several views: BASELINE config C4). Passed by value as the
+// FIRST kernel parameter and read through the kernarg segment pointer: indexing a by-value struct with a runtime view number would
+// make the compiler spill it to scratch, while the kernarg segment is uniform read-only memory (scalar loads with a dynamic offset).
+#define DVS_MAX_VIEWS 16
+struct DvsCams { DvsCam c[DVS_MAX_VIEWS]; };
+__device__ __forceinline__ DvsCam dvs_load_cam(int v) {
+    typedef const __attribute__((address_space(4))) uint32_t* KW;
+    const KW w = (KW)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)v * (sizeof(DvsCam) / 4);
+    DvsCam cam;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&cam);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(DvsCam) / 4); ++k) d[k] = w[k];
+    return cam;
+}
+
 // Deterministic exp: exp feeds integer decisions (scale -> cov -> radius -> tile rect), so it is a
 // fixed sequence of IEEE-exact operations (v_rndne, v_fma, v_mul, v_add, exponent insert), not
 // v_exp_f32. Cephes-style range reduction + degree-5 polynomial; < 2 ulp on [-87, 88].

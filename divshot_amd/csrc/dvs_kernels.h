@@ -6,8 +6,8 @@
 
 // preprocess.hip
 hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, const float* sh0, const float* shN,
-                                     const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
-                                     int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
+                                     const float* opacity, const float* scale, const float* rot, const DvsCams& cams, int n_views,
+                                     int deg, int antialias, int tiles_x, int tiles_y, int* radii /*per-view outputs are [n_views][n]*/, float* splat2d,
                                      float* depth, uint32_t* flags,
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect /*[n,2]: 4 x u16*/);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
@@ -16,6 +16,13 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
                                      float* g_pos, float* g_sh0, float* g_shN, float* g_opacity, float* g_scale,
                                      float* g_rot, float* out_absgrad2d /*nullable*/, float* out_mean2d /*nullable*/,
                                      float* out_dcolor /*nullable*/, int accumulate, int rezero_rows, int shn_tiled, int grad_mode);
+// A9 for all views of a batch in one pass (DVS_SHN_TILED layout only): radii / flags / grad_rows are [n_views][n]; writes the
+// geometry gradients (sums over the views) and out_dcolor [n_views][n][3]; the SH rows follow from dcolor (dvs_launch_sh_grad_combine)
+hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, const float* pos, const float* shN, const float* opacity,
+                                           const float* scale, const float* rot, const DvsCams& cams, int deg, int antialias,
+                                           const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos, float* g_opacity,
+                                           float* g_scale, float* g_rot, float* out_absgrad2d, float* out_mean2d, float* out_dcolor,
+                                           int accumulate, int rezero_rows, int grad_mode);
 // g_sh0 / g_shN may be nullptr in dvs_launch_preprocess_bwd (factorised exchange); this rebuilds them from dcolor[n_views,n,3].
 hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
                                       const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled);
@@ -36,8 +43,10 @@ size_t dvs_scan_scratch_words(int n);
 hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect, uint32_t* rect_sorted,
                                 uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity);
 // A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order (streams ids + sorted rectangles).
+// n = n_views * n_per_view sorted elements whose values are global indices view * n_per_view + splat; tile ids are view * tiles_per_view + tile
 hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
-                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity);
+                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity,
+                                int n_per_view, int n_views, int tiles_per_view);
 // A6: per-tile [start,end) from the sorted tile ids. T_dev (nullable): device-side count, T sizes the grid.
 hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles,
                                   const uint64_t* T_dev = nullptr, uint64_t T_expected = 0);
@@ -45,14 +54,14 @@ hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* so
 hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, const uint32_t* sorted_splat,
                                   const float* depth, uint64_t* out_keys);
 
-// render.hip
-hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color, float* final_T,
+// render.hip — one launch covers the tiles of all n_views views of a batch (view-major ranges / pixel arrays; bgs = [n_views][3])
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
                                  uint32_t* n_contrib);
-hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T, const uint32_t* n_contrib,
+hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad, int grad_mode,
-                                 int variant /*DVS_BWD_*: which A8 kernel*/);
+                                 int variant /*DVS_BWD_*: which A8 kernel (the mm experiment renders one view)*/);
 // A8 kernel variants (dvs_set_backward_variant): same inputs, same 48-B row contract, results equal to fp32 roundoff
 enum { DVS_BWD_BLOCKS = 0 /*per-4x4-block lists, four cursors per wave (experiment)*/, DVS_BWD_REDUCE = 1 /*per-quadrant masks, wave-wide
        reduction tree per visit (default: the measured winner)*/, DVS_BWD_MM = 2 /*per-quadrant masks, sums contracted on the fp32 matrix pipe (experiment)*/ };

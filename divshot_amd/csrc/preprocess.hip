@@ -66,11 +66,12 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ g, const floa
 __device__ __forceinline__ int64_t shn_tiled_f4(int i, int c) { return ((int64_t)(i >> 6) * 12 + c) * 64 + (i & 63); }
 
 // ---- A2 ---------------------------------------------------------------------------------------
-template <bool TILED>
+template <bool TILED, bool MULTI /*more than one view: the parameter registers stay live across the view loop*/>
 __global__ void __launch_bounds__(PP_BLOCK)
-k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__ sh0, const float* __restrict__ shN,
+k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through dvs_load_cam() */, int n_views, int n,
+                 const float* __restrict__ pos, const float* __restrict__ sh0, const float* __restrict__ shN,
                  const float* __restrict__ opacity, const float* __restrict__ scale, const float* __restrict__ rot,
-                 DvsCam cam, int deg, int antialias, int tiles_x, int tiles_y,
+                 int deg, int antialias, int tiles_x, int tiles_y,
                  int* __restrict__ radii, float4* __restrict__ splat2d /*[n] 64-B records, DVS_S2D_* */, float* __restrict__ depth,
                  uint32_t* __restrict__ flags,
                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
@@ -97,6 +98,12 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         __syncthreads();
     }
     if (i >= n) return;
+    (void)cams_arg;
+    // One lane per splat, all views of the batch: the 236 B of parameters are read once per iteration instead of once per view;
+    // the per-view outputs are view-major ([view][splat]: index o), the sort value is the global index.
+    for (int view = 0; view < (MULTI ? n_views : 1); ++view) {
+    const DvsCam cam = dvs_load_cam(view);
+    const int64_t o = (int64_t)view * n + i;
 
     int out_radius = 0;
     uint32_t out_tiles = 0, out_flags = 0, out_key = 0xFFFFFFFFu;
@@ -225,8 +232,8 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
         out_rect = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
     } while (0);
 
-    radii[i] = out_radius;
-    depth[i] = out_depth;
+    radii[o] = out_radius;
+    depth[o] = out_depth;
     // The projected splat as one 64-B record: the tile kernels gather it per instance, one cache line instead of three.
     // Whole lines are written (a partly written line costs a read-modify-write), and a full wave transposes its 64 records
     // through LDS so that each store instruction covers 1 KB of consecutive addresses instead of 64 quarter lines.
@@ -235,74 +242,33 @@ k_preprocess_fwd(int n, const float* __restrict__ pos, const float* __restrict__
     const float4 rc2 = make_float4(out_rgb[2], out_depth, __int_as_float(out_radius), 0.f);
     const float4 rc3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int wave_base = (int)base + (int)(threadIdx.x & ~63u);
-    if (wave_base + 64 <= n) {
+    if (wave_base + 64 <= n) {                 // (a whole wave of valid splats: uniform per wave)
         __shared__ float4 s_rec[PP_BLOCK * 4];
         float4* w = s_rec + (threadIdx.x & ~63u) * 4;           // this wave's 4 KB; wave-local, LDS ops of a wave execute in order
         const int lane = threadIdx.x & 63;
         w[lane * 4 + 0] = rc0; w[lane * 4 + 1] = rc1; w[lane * 4 + 2] = rc2; w[lane * 4 + 3] = rc3;
-        float4* dst = splat2d + 4 * (size_t)wave_base;
+        float4* dst = splat2d + 4 * ((size_t)view * n + (size_t)wave_base);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q * 64 + lane] = w[q * 64 + lane];
     } else {
-        float4* rec = splat2d + 4 * (size_t)i;
+        float4* rec = splat2d + 4 * (size_t)o;
         rec[0] = rc0; rec[1] = rc1; rec[2] = rc2; rec[3] = rc3;
     }
-    flags[i] = out_flags;
-    tiles_touched[i] = out_tiles;
-    rect[i] = out_rect;
-    depth_key[i] = out_key;
-    ids[i] = (uint32_t)i;
+    flags[o] = out_flags;
+    tiles_touched[o] = out_tiles;
+    rect[o] = out_rect;
+    depth_key[o] = out_key;
+    ids[o] = (uint32_t)o;
+    }   // views
 }
 
-// ---- A9 ---------------------------------------------------------------------------------------
-template <bool ACCUM, bool TILED>
-__global__ void __launch_bounds__(PP_BLOCK)
-k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
-                 const float* __restrict__ scale, const float* __restrict__ rot, DvsCam cam, int deg, int antialias,
-                 const int* __restrict__ radii, const uint32_t* __restrict__ flags,
-                 float4* __restrict__ grad_rows /*[n,3] float4: Sx Sy Sxx Sxy | Syy So r g | b |mx| |my| pad (A8 moments); re-zeroed here*/,
-                 float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
-                 float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
-                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor, int rezero,
-                 int grad_mode /*dvs_opts.grad_mode: 1 = DVS_GRAD_LINEAGE holds the clamped Jacobian coordinate constant*/) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
-    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
-    const int i = (int)(base + threadIdx.x);
-    const bool valid = i < n;
-    // this lane's own loads go out before the cooperative shN staging so both are in flight together
-    const int il = valid ? i : (n - 1);
-    const int radius = valid ? radii[il] : 0;
-    const float4 in_r0 = grad_rows[3 * (int64_t)il], in_r1 = grad_rows[3 * (int64_t)il + 1], in_r2 = grad_rows[3 * (int64_t)il + 2];
-    const float in_px = pos[3 * (int64_t)il], in_py = pos[3 * (int64_t)il + 1], in_pz = pos[3 * (int64_t)il + 2];
-    const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
-    const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
-    const float in_op = opacity[il];
-    const uint32_t in_fl = flags[il];
-    if (!TILED && deg > 0) {
-        stage_rows_in<45>(shN, lds, base, n);
-        __syncthreads();
-    }
-    float gp[3] = {0.f, 0.f, 0.f}, gs0[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq_out[4] = {0.f, 0.f, 0.f, 0.f};
-    float gcol[3] = {0.f, 0.f, 0.f};     // dL/d(colour), zeroed where the colour was clamped: all a peer needs to rebuild the SH rows
-    float g_op = 0.f;
-    // ROWS: the staged parameter row is overwritten in place by its gradient and leaves through LDS.
-    // TILED: parameters are read from, and gradients written to, the tiled arrays directly.
-    float* row = lds + threadIdx.x * 45;
-    const float4* p4 = reinterpret_cast<const float4*>(shN);
-    float4* g4 = reinterpret_cast<float4*>(g_shN);
-
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    float2 dm_out = make_float2(0.f, 0.f);          // dL/dmean2D (optional output)
-    if (radius > 0) {
-        r0 = in_r0; r1 = in_r1; r2 = in_r2;
-        // leave the accumulation row zeroed for the next backward (saves a 48 B/splat memset pass per view)
-        if (rezero) {
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            grad_rows[3 * (int64_t)i] = z4; grad_rows[3 * (int64_t)i + 1] = z4; grad_rows[3 * (int64_t)i + 2] = z4;
-        }
-        const float dL_dcol[3] = {r1.z, r1.w, r2.x};
-        const float px = in_px, py = in_py, pz = in_pz;
-        const uint32_t fl = in_fl;
+// The view-dependent geometry part of A9 for one (splat, view): recomputes the forward intermediates (same expressions as
+// k_preprocess_fwd), turns the A8 moments into dL/dmean2D and dL/dconic, and walks back through conic -> cov2D -> (J, W) -> Sigma ->
+// (scale, rotation) and through the projection to the position. `gp` arrives holding the SH view-direction part and leaves holding the
+// complete dL/dpos of this view (the order of the additions is the order of the fused kernel of round 1: results are bit-identical).
+__device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float py, float pz, float in_s0, float in_s1, float in_s2, float4 in_q,
+                                            float in_op, uint32_t fl, float4 r0, float4 r1, int antialias, int grad_mode, float gp[3],
+                                            float gsc[3], float gq_out[4], float& g_op, float2& dm_out) {
         const float tx = dvs_xform(cam.view, px, py, pz, 0);
         const float ty = dvs_xform(cam.view, px, py, pz, 1);
         const float tz = dvs_xform(cam.view, px, py, pz, 2);
@@ -348,64 +314,6 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float2 dL_dm = make_float2(-(cA * r0.x + cB * r0.y), -(cC * r0.y + cB * r0.x));
         const float4 gco = make_float4(-0.5f * r0.z, -r0.w, -0.5f * r1.x, r1.y);
         dm_out = dL_dm;
-
-        // 1. colour / SH
-        const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
-        const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
-        const float inv_dl = 1.0f / dl;
-        const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
-        float bas[16], dbas[16][3];
-        dvs_sh_basis(deg, ux, uy, uz, bas);
-        dvs_sh_basis_grad(deg, ux, uy, uz, dbas);
-        const int ncoef = (deg + 1) * (deg + 1);
-        float gdir[3] = {0.f, 0.f, 0.f};
-        float gc[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch];
-            gcol[ch] = gc[ch];
-            gs0[ch] = bas[0] * gc[ch];
-        }
-        if (TILED) {
-            // twelve float4 chunks: load the parameters of chunk c, emit its four gradient elements, store — nothing is staged
-#pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const int64_t idx = shn_tiled_f4(i, c);
-                float gv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (c * 4 < (ncoef - 1) * 3) {
-                    const float4 q = p4[idx];
-                    const float qv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = c * 4 + u;                     // compile-time: coefficient k = e/3 + 1, channel e%3
-                        if (e < 45 && e / 3 + 1 < ncoef) {
-                            const int k = e / 3 + 1, ch = e % 3;
-                            gv[u] = bas[k] * gc[ch];
-                            gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
-                        }
-                    }
-                }
-                if (g4) {
-                    float4 o = make_float4(gv[0], gv[1], gv[2], gv[3]);
-                    if (ACCUM) { const float4 p = g4[idx]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-                    g4[idx] = o;
-                }
-            }
-        } else {
-            for (int k = 1; k < ncoef; ++k) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float coef = row[(k - 1) * 3 + ch];
-                    row[(k - 1) * 3 + ch] = bas[k] * gc[ch];       // overwrite the staged parameter with its gradient
-                    gdir[0] += dbas[k][0] * coef * gc[ch]; gdir[1] += dbas[k][1] * coef * gc[ch]; gdir[2] += dbas[k][2] * coef * gc[ch];
-                }
-            }
-            for (int e = (ncoef - 1) * 3; e < 45; ++e) row[e] = 0.f;
-        }
-        {
-            const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
-            gp[0] += (gdir[0] - ux * ug) * inv_dl; gp[1] += (gdir[1] - uy * ug) * inv_dl; gp[2] += (gdir[2] - uz * ug) * inv_dl;
-        }
 
         // 2. opacity (+ AA)
         float g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f;
@@ -509,6 +417,116 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float qg = ((qr * gq[0] + qx * gq[1]) + qy * gq[2]) + qz * gq[3];
         gq_out[0] = (gq[0] - qr * qg) * inv_qn; gq_out[1] = (gq[1] - qx * qg) * inv_qn;
         gq_out[2] = (gq[2] - qy * qg) * inv_qn; gq_out[3] = (gq[3] - qz * qg) * inv_qn;
+}
+
+// ---- A9 ---------------------------------------------------------------------------------------
+template <bool ACCUM, bool TILED>
+__global__ void __launch_bounds__(PP_BLOCK)
+k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
+                 const float* __restrict__ scale, const float* __restrict__ rot, DvsCam cam, int deg, int antialias,
+                 const int* __restrict__ radii, const uint32_t* __restrict__ flags,
+                 float4* __restrict__ grad_rows /*[n,3] float4: Sx Sy Sxx Sxy | Syy So r g | b |mx| |my| pad (A8 moments); re-zeroed here*/,
+                 float* __restrict__ g_pos, float* __restrict__ g_sh0, float* __restrict__ g_shN,
+                 float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
+                 float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor, int rezero,
+                 int grad_mode /*dvs_opts.grad_mode: 1 = DVS_GRAD_LINEAGE holds the clamped Jacobian coordinate constant*/) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45]
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int i = (int)(base + threadIdx.x);
+    const bool valid = i < n;
+    // this lane's own loads go out before the cooperative shN staging so both are in flight together
+    const int il = valid ? i : (n - 1);
+    const int radius = valid ? radii[il] : 0;
+    const float4 in_r0 = grad_rows[3 * (int64_t)il], in_r1 = grad_rows[3 * (int64_t)il + 1], in_r2 = grad_rows[3 * (int64_t)il + 2];
+    const float in_px = pos[3 * (int64_t)il], in_py = pos[3 * (int64_t)il + 1], in_pz = pos[3 * (int64_t)il + 2];
+    const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
+    const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
+    const float in_op = opacity[il];
+    const uint32_t in_fl = flags[il];
+    if (!TILED && deg > 0) {
+        stage_rows_in<45>(shN, lds, base, n);
+        __syncthreads();
+    }
+    float gp[3] = {0.f, 0.f, 0.f}, gs0[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq_out[4] = {0.f, 0.f, 0.f, 0.f};
+    float gcol[3] = {0.f, 0.f, 0.f};     // dL/d(colour), zeroed where the colour was clamped: all a peer needs to rebuild the SH rows
+    float g_op = 0.f;
+    // ROWS: the staged parameter row is overwritten in place by its gradient and leaves through LDS.
+    // TILED: parameters are read from, and gradients written to, the tiled arrays directly.
+    float* row = lds + threadIdx.x * 45;
+    const float4* p4 = reinterpret_cast<const float4*>(shN);
+    float4* g4 = reinterpret_cast<float4*>(g_shN);
+
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    float2 dm_out = make_float2(0.f, 0.f);          // dL/dmean2D (optional output)
+    if (radius > 0) {
+        r0 = in_r0; r1 = in_r1; r2 = in_r2;
+        // leave the accumulation row zeroed for the next backward (saves a 48 B/splat memset pass per view)
+        if (rezero) {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            grad_rows[3 * (int64_t)i] = z4; grad_rows[3 * (int64_t)i + 1] = z4; grad_rows[3 * (int64_t)i + 2] = z4;
+        }
+        const float dL_dcol[3] = {r1.z, r1.w, r2.x};
+        const float px = in_px, py = in_py, pz = in_pz;
+        const uint32_t fl = in_fl;
+        // 1. colour / SH
+        const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
+        const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+        const float inv_dl = 1.0f / dl;
+        const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
+        float bas[16], dbas[16][3];
+        dvs_sh_basis(deg, ux, uy, uz, bas);
+        dvs_sh_basis_grad(deg, ux, uy, uz, dbas);
+        const int ncoef = (deg + 1) * (deg + 1);
+        float gdir[3] = {0.f, 0.f, 0.f};
+        float gc[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch];
+            gcol[ch] = gc[ch];
+            gs0[ch] = bas[0] * gc[ch];
+        }
+        if (TILED) {
+            // twelve float4 chunks: load the parameters of chunk c, emit its four gradient elements, store — nothing is staged
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const int64_t idx = shn_tiled_f4(i, c);
+                float gv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (c * 4 < (ncoef - 1) * 3) {
+                    const float4 q = p4[idx];
+                    const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = c * 4 + u;                     // compile-time: coefficient k = e/3 + 1, channel e%3
+                        if (e < 45 && e / 3 + 1 < ncoef) {
+                            const int k = e / 3 + 1, ch = e % 3;
+                            gv[u] = bas[k] * gc[ch];
+                            gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                        }
+                    }
+                }
+                if (g4) {
+                    float4 o = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                    if (ACCUM) { const float4 p = g4[idx]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                    g4[idx] = o;
+                }
+            }
+        } else {
+            for (int k = 1; k < ncoef; ++k) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float coef = row[(k - 1) * 3 + ch];
+                    row[(k - 1) * 3 + ch] = bas[k] * gc[ch];       // overwrite the staged parameter with its gradient
+                    gdir[0] += dbas[k][0] * coef * gc[ch]; gdir[1] += dbas[k][1] * coef * gc[ch]; gdir[2] += dbas[k][2] * coef * gc[ch];
+                }
+            }
+            for (int e = (ncoef - 1) * 3; e < 45; ++e) row[e] = 0.f;
+        }
+        {
+            const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
+            gp[0] += (gdir[0] - ux * ug) * inv_dl; gp[1] += (gdir[1] - uy * ug) * inv_dl; gp[2] += (gdir[2] - uz * ug) * inv_dl;
+        }
+
+        a9_geometry(cam, px, py, pz, in_s0, in_s1, in_s2, in_q, in_op, fl, r0, r1, antialias, grad_mode, gp, gsc, gq_out, g_op, dm_out);
     } else if (valid) {
         if (TILED) {
             if (g4 && !ACCUM) {
@@ -563,6 +581,134 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
     if (g_sh0) stage_rows_out<3, ACCUM>(g_sh0, l_sh0, base, n);
     stage_rows_out<3, ACCUM>(g_scale, l_scl, base, n);
     if (out_dcolor) stage_rows_out<3, false>(out_dcolor, l_col, base, n);
+}
+
+// ---- A9 over the views of a batch (DVS_SHN_TILED layout) -----------------------------------------------------------------
+// One lane per splat, all views of the iteration: the parameters are read once, every view adds its contribution to register
+// accumulators, and the geometry gradients (pos, scale, rot, opacity: 44 B) are written once — instead of a read-modify-write of the
+// gradient rows per view. The SH rows are rank-1 in the per-view colour gradient, so this kernel only emits that (dcolor, 12 B per
+// splat and view) and k_sh_grad_combine builds sh0 / shN from it afterwards — on one GPU right away, in data-parallel runs after the
+// all-gather of dcolor (the factorised exchange), with the same kernel. Per view the same expressions in the same order as
+// k_preprocess_bwd, so the geometry gradients of a batch are bit-identical to its views run one by one with opts.accumulate.
+template <bool ACCUM>
+__global__ void __launch_bounds__(PP_BLOCK)
+k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read through dvs_load_cam() */, int n_views, int n,
+                       const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
+                       const float* __restrict__ scale, const float* __restrict__ rot, int deg, int antialias,
+                       const int* __restrict__ radii /*[V,n]*/, const uint32_t* __restrict__ flags /*[V,n]*/,
+                       float4* __restrict__ grad_rows /*[V,n,3]: A8 moments; re-zeroed here*/,
+                       float* __restrict__ g_pos, float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
+                       float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor /*[V,n,3]*/,
+                       int rezero, int grad_mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*6]
+    (void)cams_arg;
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int i = (int)(base + threadIdx.x);
+    const bool valid = i < n;
+    const int il = valid ? i : (n - 1);
+    const float px = pos[3 * (int64_t)il], py = pos[3 * (int64_t)il + 1], pz = pos[3 * (int64_t)il + 2];
+    const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
+    const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
+    const float in_op = opacity[il];
+    const int ncoef = (deg + 1) * (deg + 1);
+    const float4* p4 = reinterpret_cast<const float4*>(shN);
+    float gp[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    float g_op = 0.f;
+    float2 ag = make_float2(0.f, 0.f), dm = make_float2(0.f, 0.f);
+    float* l_col = lds;
+
+    for (int view = 0; view < n_views; ++view) {
+        const DvsCam cam = dvs_load_cam(view);
+        const int64_t o = (int64_t)view * n + il;
+        const int radius = valid ? radii[o] : 0;
+        float gcol[3] = {0.f, 0.f, 0.f};
+        if (radius > 0) {
+            const float4 r0 = grad_rows[3 * o], r1 = grad_rows[3 * o + 1], r2 = grad_rows[3 * o + 2];
+            if (rezero) {
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                grad_rows[3 * o] = z4; grad_rows[3 * o + 1] = z4; grad_rows[3 * o + 2] = z4;
+            }
+            const uint32_t fl = flags[o];
+            const float dL_dcol[3] = {r1.z, r1.w, r2.x};
+            // 1. colour -> view direction (same expressions and order as k_preprocess_bwd; the SH rows themselves: k_sh_grad_combine)
+            const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
+            const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
+            const float inv_dl = 1.0f / dl;
+            const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
+            float dbas[16][3];
+            dvs_sh_basis_grad(deg, ux, uy, uz, dbas);
+            float gdir[3] = {0.f, 0.f, 0.f};
+            float gc[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch]; gcol[ch] = gc[ch]; }
+            // the coefficients come from the tiled array again for every view: after the first view they are L2 hits, and keeping
+            // 48 of them in registers across the loop would halve the occupancy
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                if (c * 4 < (ncoef - 1) * 3) {
+                    const float4 q = p4[shn_tiled_f4(i, c)];
+                    const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = c * 4 + u;                     // compile-time: coefficient k = e/3 + 1, channel e%3
+                        if (e < 45 && e / 3 + 1 < ncoef) {
+                            const int k = e / 3 + 1, ch = e % 3;
+                            gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                        }
+                    }
+                }
+            }
+            float gpv[3] = {0.f, 0.f, 0.f}, gscv[3], gqv[4], g_opv;
+            float2 dmv;
+            {
+                const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
+                gpv[0] += (gdir[0] - ux * ug) * inv_dl; gpv[1] += (gdir[1] - uy * ug) * inv_dl; gpv[2] += (gdir[2] - uz * ug) * inv_dl;
+            }
+            a9_geometry(cam, px, py, pz, in_s0, in_s1, in_s2, in_q, in_op, fl, r0, r1, antialias, grad_mode, gpv, gscv, gqv, g_opv, dmv);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gp[k] += gpv[k]; gsc[k] += gscv[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gq[k] += gqv[k];
+            g_op += g_opv;
+            ag.x += r2.y; ag.y += r2.z;
+            dm.x += dmv.x; dm.y += dmv.y;
+        }
+        // per-view colour gradient, always overwritten (zero for culled splats and clamped channels)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l_col[threadIdx.x * 3 + k] = gcol[k];
+        __syncthreads();
+        stage_rows_out<3, false>(out_dcolor + (size_t)view * n * 3, l_col, base, n);
+    }
+
+    if (valid) {
+        if (out_absgrad2d) {
+            float2 a = ag;
+            if (ACCUM) { const float2 q = out_absgrad2d[i]; a.x += q.x; a.y += q.y; }
+            out_absgrad2d[i] = a;
+        }
+        if (out_mean2d) {
+            float2 mm = dm;
+            if (ACCUM) { const float2 q = out_mean2d[i]; mm.x += q.x; mm.y += q.y; }
+            out_mean2d[i] = mm;
+        }
+        if (ACCUM) {
+            g_opacity[i] += g_op;
+            float4 q = reinterpret_cast<float4*>(g_rot)[i];
+            q.x += gq[0]; q.y += gq[1]; q.z += gq[2]; q.w += gq[3];
+            reinterpret_cast<float4*>(g_rot)[i] = q;
+        } else {
+            g_opacity[i] = g_op;
+            reinterpret_cast<float4*>(g_rot)[i] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        }
+    }
+    __syncthreads();
+    float* l_pos = lds, *l_scl = lds + PP_BLOCK * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { l_pos[threadIdx.x * 3 + k] = gp[k]; l_scl[threadIdx.x * 3 + k] = gsc[k]; }
+    __syncthreads();
+    stage_rows_out<3, ACCUM>(g_pos, l_pos, base, n);
+    stage_rows_out<3, ACCUM>(g_scale, l_scl, base, n);
 }
 
 // ---- factorised SH gradient: rows from per-view colour gradients -----------------------------------------------------
@@ -695,21 +841,21 @@ k_shn_relayout(int n, const float* __restrict__ src, float* __restrict__ dst, in
 
 // ---- launchers -----------------------------------------------------------------------------------
 hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, const float* sh0, const float* shN,
-                                     const float* opacity, const float* scale, const float* rot, const DvsCam& cam,
+                                     const float* opacity, const float* scale, const float* rot, const DvsCams& cams, int n_views,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
                                      float* depth, uint32_t* flags,
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     if (shn_tiled) {
-        hipLaunchKernelGGL(k_preprocess_fwd<true>, dim3(grid), dim3(PP_BLOCK), 0, st, n, pos, sh0, shN, opacity, scale, rot, cam,
-                           deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,
-                           tiles_touched, depth_key, ids, (uint2*)rect);
+#define DVS_A2(T, M, LDS) hipLaunchKernelGGL((k_preprocess_fwd<T, M>), dim3(grid), dim3(PP_BLOCK), LDS, st, cams, n_views, n, pos, sh0, shN, opacity, \
+                                             scale, rot, deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,          \
+                                             tiles_touched, depth_key, ids, (uint2*)rect)
+        if (n_views > 1) DVS_A2(true, true, 0); else DVS_A2(true, false, 0);
     } else {
         const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;
-        hipLaunchKernelGGL(k_preprocess_fwd<false>, dim3(grid), dim3(PP_BLOCK), lds, st, n, pos, sh0, shN, opacity, scale, rot, cam,
-                           deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,
-                           tiles_touched, depth_key, ids, (uint2*)rect);
+        if (n_views > 1) DVS_A2(false, true, lds); else DVS_A2(false, false, lds);
+#undef DVS_A2
     }
     return hipGetLastError();
 }
@@ -731,6 +877,23 @@ hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, co
     if (accumulate) { if (shn_tiled) DVS_PPB(true, true); else DVS_PPB(true, false); }
     else { if (shn_tiled) DVS_PPB(false, true); else DVS_PPB(false, false); }
 #undef DVS_PPB
+    return hipGetLastError();
+}
+
+hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, const float* pos, const float* shN, const float* opacity,
+                                           const float* scale, const float* rot, const DvsCams& cams, int deg, int antialias,
+                                           const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos, float* g_opacity,
+                                           float* g_scale, float* g_rot, float* out_absgrad2d, float* out_mean2d, float* out_dcolor,
+                                           int accumulate, int rezero, int grad_mode) {
+    if (n <= 0 || n_views <= 0) return hipSuccess;
+    const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const size_t lds = (size_t)PP_BLOCK * 6 * sizeof(float);
+#define DVS_PPV(A)                                                                                                              \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<A>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
+                       deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_opacity, g_scale, g_rot,                         \
+                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero, grad_mode)
+    if (accumulate) DVS_PPV(true); else DVS_PPV(false);
+#undef DVS_PPV
     return hipGetLastError();
 }
 

@@ -100,19 +100,25 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 
 // ---- A7 -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RB)
-k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
-             float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
+             int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
+             const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
+             float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib) {
     __shared__ BatchLds L;
-    const int tile = tile_of_block(blockIdx.x, num_tiles);
-    if (tile >= num_tiles) return;
+    (void)bg_arg;
+    const int tile_g = tile_of_block(blockIdx.x, num_tiles);
+    if (tile_g >= num_tiles) return;
+    const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
+    const float3 bgv = dvs_load_bg(view);
+    const float bg0 = bgv.x, bg1 = bgv.y, bg2 = bgv.z;
+    out_color += (size_t)view * 3 * W * H; final_T += (size_t)view * W * H; n_contrib += (size_t)view * W * H;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * DVS_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * DVS_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
+    const uint2 range = ranges[tile_g];
     const int total = (int)(range.y - range.x);
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -168,22 +174,28 @@ k_render_fwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__
 // ---- A8 -------------------------------------------------------------------------------------------
 template <bool ABSGRAD>
 __global__ void __launch_bounds__(RB)
-k_render_bwd(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
-             const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
+k_render_bwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
+             int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
+             const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
+             const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
              float* __restrict__ grow /*[n,12]: Sx Sy Sxx Sxy Syy So r g b |mx| |my| pad (moments, see the loop body)*/,
              int lineage /*dvs_opts.grad_mode == DVS_GRAD_LINEAGE: the gradient passes the 0.99 alpha cap*/) {
     __shared__ BatchLds L;
     __shared__ uint32_t s_max[RB / 64];
-    const int tile = tile_of_block(blockIdx.x, num_tiles);
-    if (tile >= num_tiles) return;
+    (void)bg_arg;
+    const int tile_g = tile_of_block(blockIdx.x, num_tiles);
+    if (tile_g >= num_tiles) return;
+    const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
+    const float3 bgv = dvs_load_bg(view);
+    const float bg0 = bgv.x, bg1 = bgv.y, bg2 = bgv.z;
+    final_T += (size_t)view * W * H; n_contrib += (size_t)view * W * H; dL_dout += (size_t)view * 3 * W * H;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * DVS_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * DVS_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
+    const uint2 range = ranges[tile_g];
     const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
     // which reduced value this lane publishes: lane c (< 3) of row r carries q[c] = value kv (see wave_reduce12)
     const int lrow = lane >> 4, lcol = lane & 15;
@@ -496,22 +508,27 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
-hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color, float* final_T,
+static ViewBg make_view_bg(int n_views, const float* bgs /*[n_views][3]*/) {
+    ViewBg b{};
+    for (int v = 0; v < n_views && v < DVS_MAX_VIEWS; ++v) for (int k = 0; k < 3; ++k) b.bg[v][k] = bgs[3 * v + k];
+    return b;
+}
+
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
                                  uint32_t* n_contrib) {
-    const int num_tiles = tiles_x * tiles_y;
+    const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,
-                       (const float4*)splat2d, bg[0], bg[1], bg[2], out_color, final_T,
-                       n_contrib);
+    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
+                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib);
     return hipGetLastError();
 }
 
-hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                 const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T, const uint32_t* n_contrib,
+hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                 const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows, int absgrad, int grad_mode, int variant) {
-    const int num_tiles = tiles_x * tiles_y;
+    const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
@@ -519,11 +536,18 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
     const char* e_lds = getenv("DVS_BWD_EXTRA_LDS"); const char* e_dbg = getenv("DVS_MM_DEBUG");
     const size_t extra_lds = e_lds ? (size_t)atoi(e_lds) : 0;
     const int dbg = e_dbg ? atoi(e_dbg) : 0;
-#define DVS_RB(KERNEL, ...)                                                                                                          \
-    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat,        \
-                       (const float4*)splat2d, bg[0], bg[1], bg[2], final_T, n_contrib, dL_dout, grad_rows, lineage, ##__VA_ARGS__)
-    if (variant == DVS_BWD_REDUCE) { if (absgrad) DVS_RB(k_render_bwd<true>); else DVS_RB(k_render_bwd<false>); }
-    else { if (absgrad) DVS_RB(k_render_bwd_mm<true>, dbg); else DVS_RB(k_render_bwd_mm<false>, dbg); }
+    if (variant == DVS_BWD_REDUCE) {
+#define DVS_RB(KERNEL)                                                                                                             \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles, \
+                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, lineage)
+        if (absgrad) DVS_RB(k_render_bwd<true>); else DVS_RB(k_render_bwd<false>);
 #undef DVS_RB
+    } else {                                             // the mm experiment: one view
+#define DVS_RM(KERNEL)                                                                                                          \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat, \
+                       (const float4*)splat2d, bgs[0], bgs[1], bgs[2], final_T, n_contrib, dL_dout, grad_rows, lineage, dbg)
+        if (absgrad) DVS_RM(k_render_bwd_mm<true>); else DVS_RM(k_render_bwd_mm<false>);
+#undef DVS_RM
+    }
     return hipGetLastError();
 }

@@ -4,6 +4,15 @@
 
 #define RB 256
 
+// Per-view backgrounds of a multi-view batch: FIRST kernel parameter of the composite kernels, read through the kernarg segment
+// pointer (see DvsCams in dvs_device.h). One launch covers the tiles of all views: global tile t = view * tiles_per_view + tile.
+struct ViewBg { float bg[DVS_MAX_VIEWS][4]; };
+__device__ __forceinline__ float3 dvs_load_bg(int v) {
+    typedef const __attribute__((address_space(4))) float* KF;
+    const KF f = (KF)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)v * 4;
+    return make_float3(f[0], f[1], f[2]);
+}
+
 // blockIdx -> tile: consecutive workgroups land on different XCDs (b % 8), so give each XCD a
 // contiguous band of tiles; neighbouring tiles share splats and therefore L2 lines.
 __device__ __forceinline__ int tile_of_block(int b, int num_tiles) {

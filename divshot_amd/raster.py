@@ -38,12 +38,13 @@ def _stream_ptr():
 
 
 class Rasterizer:
-    def __init__(self, device=0, max_splats=1 << 20, max_w=1920, max_h=1080):
+    def __init__(self, device=0, max_splats=1 << 20, max_w=1920, max_h=1080, max_views=1):
         if not torch.cuda.is_available():
             raise DvsError("no HIP device visible: the rasterizer has no CPU fallback")
         self.device = device
         self.tdev = torch.device("cuda", device)
-        self.ctx = lib.dvs_create(device, max_splats, max_w, max_h)
+        self.max_views = max_views
+        self.ctx = lib.dvs_create_views(device, max_splats, max_w, max_h, max_views)
         if not self.ctx:
             raise DvsError("dvs_create failed: " + lib.dvs_last_error().decode())
         self.state = None
@@ -141,8 +142,70 @@ class Rasterizer:
             check(lib.dvs_raster_forward(self.ctx, _stream_ptr(), C.byref(sp), C.byref(cam), C.byref(opts),
                                          out.data_ptr(), C.byref(st), C.byref(T)), "dvs_raster_forward")
         self.state, self._cam, self._opts, self._params = st, cam, opts, params
+        self._cams = None                              # (single view: the split backward calls take the one camera)
         self.num_rendered = int(T.value)
         return out
+
+    # -- multi-view batches (dvs_raster_forward_views / dvs_raster_backward_views) -----------------------------------
+    def forward_views(self, params, cams, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False, grad_mode=0):
+        """cams: list of Camera (same image size). Returns out_rgb [V,3,H,W] (CUDA). One depth sort / scan / (view, tile) sort /
+        composite launch for the whole batch; the parameters are read once."""
+        V = len(cams)
+        sp = self._splats(params, shn_tiled)
+        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled), int(grad_mode))
+        self._tiled = bool(shn_tiled)
+        if out is None:
+            out = torch.empty((V, 3, cams[0].height, cams[0].width), dtype=torch.float32, device=self.tdev)
+        carr = (Camera * V)(*cams)
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_forward_views(self.ctx, _stream_ptr(), C.byref(sp), carr, V, C.byref(opts), out.data_ptr()), "dvs_raster_forward_views")
+        st = FwdState()
+        check(lib.dvs_get_view_state(self.ctx, 0, C.byref(st)), "dvs_get_view_state")
+        self.state, self._cam, self._cams, self._opts, self._params = st, cams[0], carr, opts, params
+        self.num_rendered = int(st.num_rendered)
+        return out
+
+    def backward_views(self, dL_drgb, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
+        """dL_drgb: CUDA [V,3,H,W]. Gradient rows = the sum over the views of the last forward_views; grads["dcolor"] (factorised_sh or
+        given) is [V,n,3]."""
+        V = len(self._cams)
+        n = self._params["pos"].shape[0]
+        if factorised_sh and (grads is None or "dcolor" not in grads):
+            grads = dict(grads or {}); grads["dcolor"] = torch.empty((V, n, 3), dtype=torch.float32, device=self.tdev)
+        had = grads is not None and any(k in grads for k in PARAM_KEYS)
+        if not had:
+            base = {k: (torch.zeros_like(self._params[k]) if (k == "shN" and self._tiled) else torch.empty_like(self._params[k])) for k in PARAM_KEYS}
+            base.update(grads or {}); grads = base; accumulate = False
+        grads, opts, g = self._grad_args(grads, accumulate, want_mean2d, factorised_sh)
+        sp = self._splats(self._params, self._tiled)
+        assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous() and dL_drgb.shape[0] == V
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_backward_views(self.ctx, _stream_ptr(), C.byref(sp), self._cams, V, C.byref(opts), dL_drgb.data_ptr(), C.byref(g)),
+                  "dvs_raster_backward_views")
+        return grads
+
+    def view_saved(self, v):
+        """Host copies of view v's saved arrays of the last forward_views; the instance list of the view is cut out of the batch-wide
+        sorted lists with its tile ranges and its values are made view-local splat ids again (comparable with a single-view run)."""
+        st = FwdState()
+        check(lib.dvs_get_view_state(self.ctx, v, C.byref(st)), "dvs_get_view_state")
+        if self.state.num_rendered == 2 ** 64 - 1:
+            self.get_num_rendered()
+        n, W, H, tiles = st.n, st.width, st.height, st.tiles_x * st.tiles_y
+        T = self.state.num_rendered
+        rec = self._d2h(st.splat2d, (n, 16), np.float32)
+        ranges = self._d2h(st.ranges, (tiles, 2), np.uint32).astype(np.int64)
+        all_tile = self._d2h(st.sorted_tile, (T,), np.uint32); all_splat = self._d2h(st.sorted_splat, (T,), np.uint32)
+        nz = ranges[:, 1] > ranges[:, 0]
+        lo = int(ranges[nz, 0].min()) if nz.any() else 0
+        hi = int(ranges[nz, 1].max()) if nz.any() else 0
+        loc = ranges.copy(); loc[nz] -= lo; loc[~nz] = 0
+        return {"radii": self._d2h(st.radii, (n,), np.int32), "mean2d": rec[:, 0:2].copy(), "depth": self._d2h(st.depth, (n,), np.float32),
+                "conic_opacity": rec[:, 2:6].copy(), "rgb": rec[:, 6:9].copy(), "flags": self._d2h(st.flags, (n,), np.uint32),
+                "tiles_touched": self._d2h(st.tiles_touched, (n,), np.uint32),
+                "sorted_tile": all_tile[lo:hi] - np.uint32(v * tiles), "vals": all_splat[lo:hi] - np.uint32(v * n),
+                "ranges": loc.astype(np.uint32), "final_T": self._d2h(st.final_T, (H, W), np.float32),
+                "n_contrib": self._d2h(st.n_contrib, (H, W), np.uint32)}
 
     def _grad_args(self, grads, accumulate, want_mean2d, factorised_sh):
         params = self._params
@@ -185,16 +248,18 @@ class Rasterizer:
         """A8 alone (dvs_raster_backward_composite): touches only this context's intermediate rows."""
         assert self.state is not None, "forward first"
         assert dL_drgb.is_cuda and dL_drgb.dtype == torch.float32 and dL_drgb.is_contiguous()
+        cam_arg = self._cams if getattr(self, "_cams", None) is not None else C.byref(self._cam)      # after forward_views: all its cameras
         with torch.cuda.device(self.tdev):
-            check(lib.dvs_raster_backward_composite(self.ctx, _stream_ptr(), C.byref(self._cam), C.byref(self._opts), dL_drgb.data_ptr()),
+            check(lib.dvs_raster_backward_composite(self.ctx, _stream_ptr(), cam_arg, C.byref(self._opts), dL_drgb.data_ptr()),
                   "dvs_raster_backward_composite")
 
     def backward_project(self, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
         """A9 alone (dvs_raster_backward_project) after backward_composite; same arguments and result as backward()."""
         grads, opts, g = self._grad_args(grads, accumulate, want_mean2d, factorised_sh)
         sp = self._splats(self._params, self._tiled)
+        cam_arg = self._cams if getattr(self, "_cams", None) is not None else C.byref(self._cam)
         with torch.cuda.device(self.tdev):
-            check(lib.dvs_raster_backward_project(self.ctx, _stream_ptr(), C.byref(sp), C.byref(self._cam), C.byref(opts), C.byref(g)),
+            check(lib.dvs_raster_backward_project(self.ctx, _stream_ptr(), C.byref(sp), cam_arg, C.byref(opts), C.byref(g)),
                   "dvs_raster_backward_project")
         return grads
 

@@ -177,7 +177,9 @@ int dvs_raster_backward(dvs_ctx* ctx, void* stream, const dvs_splats* params, co
  *                composite backward of view v+1 may run concurrently with anything of view v;
  *   _project   : A9 — turns those rows into parameter gradients. With opts->accumulate it adds into `out` non-atomically, so
  *                the _project calls that share gradient arrays must be ordered (an event between streams); nothing else must.
- * dvs_raster_backward == _composite followed by _project on the same stream (bit-identical results). */
+ * dvs_raster_backward == _composite followed by _project on the same stream (bit-identical results).
+ * After dvs_raster_forward_views both calls cover all views of that forward: `cam` then points to its n_views cameras, dL_drgb is
+ * [n_views,3,H,W] and out follows dvs_raster_backward_views. */
 int dvs_raster_backward_composite(dvs_ctx* ctx, void* stream, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb);
 int dvs_raster_backward_project(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                                 const dvs_opts* opts, const dvs_splat_grads* out);
@@ -191,6 +193,26 @@ int dvs_sh_grad_combine(dvs_ctx* ctx, void* stream, int n, const float* pos, int
                         const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_layout);
 /* Convert an shN array (DEVICE, src != dst) between DVS_SHN_ROWS [n*45] and DVS_SHN_TILED [ceil(n/64)*64*48]. */
 int dvs_shn_relayout(dvs_ctx* ctx, void* stream, int n, const float* src, float* dst, int to_tiled);
+
+/* Multi-view batches (BASELINE config C4: several cameras per training iteration). A context created with dvs_create_views renders
+ * up to max_views (<= 16) views of ONE parameter block per call: the parameters are read once for all views (A2, A9), one depth sort,
+ * one scan, one duplication, one (view, tile) sort and one composite launch cover the whole batch, and the backward reads the
+ * parameters and writes the gradient rows ONCE (the sum over the views) instead of a read-modify-write per view.
+ *   cams      HOST array [n_views], all views with the same image size
+ *   out_rgb   DEVICE [n_views,3,H,W];   dL_drgb DEVICE [n_views,3,H,W]
+ *   out       gradient rows = the sum over the views (opts->accumulate adds to what is there); out->dcolor, when given, is
+ *             [n_views,n,3] (one colour gradient per view: what the factorised data-parallel exchange all-gathers); absgrad2d / mean2d
+ *             are the sums over the views of the per-view statistics
+ * Results equal the views run one by one with opts.accumulate: image / saved state bit for bit, geometry gradients bit for bit, SH rows
+ * to fp32 roundoff. dvs_get_view_state returns view v's slice of the saved state (per-splat, per-pixel and per-tile arrays; the sorted
+ * instance lists stay batch-wide: ranges index into them and their values are v * n + splat). The single-view calls are the
+ * n_views = 1 case of the same code path. */
+dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, int max_views);
+int dvs_raster_forward_views(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cams, int n_views,
+                             const dvs_opts* opts, float* out_rgb);
+int dvs_raster_backward_views(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cams, int n_views,
+                              const dvs_opts* opts, const float* dL_drgb, const dvs_splat_grads* out);
+int dvs_get_view_state(dvs_ctx* ctx, int view, dvs_fwd_state* state);
 
 /* Asynchronous forward. By default dvs_raster_forward synchronises `stream` once (it reads the instance count T to size the sort).
  * With dvs_set_async(ctx, 1) it never synchronises: the instance arena is over-allocated, T stays on the device and every kernel over

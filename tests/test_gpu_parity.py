@@ -608,3 +608,70 @@ def test_async_forward_no_host_sync(gpu_device):
     torch.cuda.synchronize()
     assert torch.equal(img, ref)
     small.close(); small2.close()
+
+
+@pytest.mark.parametrize("tiled", [True, False])
+def test_multi_view_batch_equals_single_views(gpu_device, tiled):
+    """dvs_raster_forward_views / _backward_views (BASELINE config C4: several cameras per iteration in ONE pass — parameters read once,
+    one depth sort / scan / (view, tile) sort / composite launch, gradients written once) against the same views run one by one with
+    opts.accumulate: images and every saved per-view array bit for bit (the per-view instance list is cut out of the batch-wide
+    sorted list), gradients to fp32-atomics roundoff, per-view colour gradients (factorised exchange) likewise."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H, V = 5003, 208, 120, 3
+    spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=4, seed=31)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, i + 1) for i in range(V)]
+    for i, c_ in enumerate(cams):
+        c_.bg[0], c_.bg[1], c_.bg[2] = 0.1 * i, 0.2, 0.3 + 0.1 * i          # per-view backgrounds
+    tg = [torch.from_numpy(dv.synth_target(spec, i + 1)).cuda() for i in range(V)]
+    single = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    batch = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+    Pd = params_to_device(P, single.tdev)
+    if tiled:
+        Pd = dict(Pd); Pd["shN"] = single.shn_relayout(Pd["shN"], n, to_tiled=True)
+    ref_imgs, ref_saved, ref_dcol, ref = [], [], [], None
+    for v in range(V):
+        img = single.forward(Pd, cams[v], sh_degree=3, absgrad=True, shn_tiled=tiled)
+        ref_imgs.append(img.clone()); ref_saved.append(single.saved())
+        dL = ((img - tg[v]) / (W * H)).contiguous()
+        ref = single.backward(dL, grads=ref, accumulate=ref is not None, want_mean2d=True)
+        ref_dcol.append(single.backward(dL, factorised_sh=True)["dcolor"].clone())
+        if v == 0:
+            ref = {k: t.clone() for k, t in ref.items()}
+    imgs = batch.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=tiled)
+    torch.cuda.synchronize()
+    assert batch.num_rendered == sum(s_["vals"].size for s_ in ref_saved)
+    for v in range(V):
+        assert torch.equal(imgs[v], ref_imgs[v]), f"image of view {v}"
+        sv = batch.view_saved(v)
+        for k in ("radii", "flags", "tiles_touched", "vals", "sorted_tile", "ranges", "n_contrib"):
+            np.testing.assert_array_equal(sv[k], ref_saved[v][k], err_msg=f"view {v} {k}")
+        for k in ("mean2d", "depth", "conic_opacity", "rgb", "final_T"):
+            assert np.array_equal(sv[k].view(np.uint32), ref_saved[v][k].view(np.uint32)), f"view {v} {k}"
+    dL_all = torch.stack([(imgs[v] - tg[v]) / (W * H) for v in range(V)]).contiguous()
+    g = batch.backward_views(dL_all, want_mean2d=True)
+    torch.cuda.synchronize()
+    for k in list(KEYS) + ["absgrad2d", "mean2d"]:
+        m, worst = rel_close(g[k].cpu().numpy(), ref[k].cpu().numpy(), 1e-4, 2e-6)
+        assert m.all(), (k, worst)
+    # factorised: per-view colour gradients instead of SH rows; accumulate adds a second copy of the geometry rows
+    g2 = {k: g[k].clone() for k in ("pos", "scale", "rot", "opacity")}
+    g2["dcolor"] = torch.empty((V, n, 3), device=batch.tdev)
+    batch.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=tiled)
+    batch.backward_views(dL_all, grads=g2, accumulate=True, factorised_sh=True)
+    torch.cuda.synchronize()
+    for v in range(V):
+        m, worst = rel_close(g2["dcolor"][v].cpu().numpy(), ref_dcol[v].cpu().numpy(), 1e-4, 2e-6)
+        assert m.all(), (v, worst)
+    for k in ("pos", "scale", "rot", "opacity"):
+        m, worst = rel_close(g2[k].cpu().numpy(), 2 * ref[k].cpu().numpy(), 1e-4, 2e-6)
+        assert m.all(), (k, worst)
+    # asynchronous forward (device-side T) works for batches too
+    batch.set_async(True)
+    imgs_a = batch.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=tiled)
+    assert batch.get_num_rendered() == sum(s_["vals"].size for s_ in ref_saved)
+    assert torch.equal(imgs_a, imgs)
+    with pytest.raises(dv.DvsError, match="max_views"):
+        single.forward_views(Pd, cams, sh_degree=3, shn_tiled=tiled)
+    single.close(); batch.close()
