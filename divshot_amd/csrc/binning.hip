@@ -252,21 +252,34 @@ k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __r
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(SORT_BLOCK)
+#define SCANB_THREADS 1024
+__global__ void __launch_bounds__(SCANB_THREADS)
 k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint64_t* __restrict__ total /*[0] = T, [1] += (T > capacity)*/,
                    uint64_t capacity) {
-    // one workgroup, one round: thread t owns a contiguous chunk of the block sums (a 256-at-a-time loop costs ~0.6 us per round:
-    // 16 rounds at 1M splats), sums it, the 256 chunk sums are scanned once, then the chunk is rewritten as exclusive offsets
-    __shared__ uint32_t tmp[SORT_WAVES + 1];
-    const uint32_t per = (num_blocks + SORT_BLOCK - 1) / SORT_BLOCK;
+    // one workgroup of 1024 threads, one round: thread t owns a contiguous chunk of the block sums, sums it, the chunk sums are scanned
+    // once (16 waves), then the chunk is rewritten as exclusive offsets. (A multi-view batch has 31 k block sums: 31 per thread.)
+    __shared__ uint32_t tmp[SCANB_THREADS / 64];
+    const uint32_t per = (num_blocks + SCANB_THREADS - 1) / SCANB_THREADS;
     const uint32_t lo = threadIdx.x * per, hi = min(num_blocks, lo + per);
     __shared__ unsigned long long wide;                  // the true 64-bit total: T >= 2^32 or > capacity is an error (offsets are 32-bit)
     if (threadIdx.x == 0) wide = 0ull;
     uint32_t s = 0;
     unsigned long long s64 = 0ull;
     for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = block_sums[i]; s += v; s64 += v; }
-    uint32_t tot;
-    uint32_t run = block_excl_scan(s, tmp, &tot);        // (contains the __syncthreads that publish `wide = 0`)
+    // exclusive scan of one value per thread over the 16 waves (contains the __syncthreads that publish `wide = 0`)
+    uint32_t run;
+    {
+        const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+        uint32_t inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+        if (lane == 63) tmp[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w = 0; w < SCANB_THREADS / 64; ++w) { const uint32_t t = tmp[w]; if ((uint32_t)w < wave) wbase += t; }
+        run = wbase + inc - s;
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s64 += __shfl_xor(s64, d, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&wide, s64);
@@ -281,7 +294,7 @@ hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_id
                                 uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
     if (nb > 0) hipLaunchKernelGGL(k_tile_blocksum, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect, (uint2*)rect_sorted, block_offsets);
-    hipLaunchKernelGGL(k_tile_scan_blocks, dim3(1), dim3(SORT_BLOCK), 0, st, block_offsets, nb, total_dev, capacity);
+    hipLaunchKernelGGL(k_tile_scan_blocks, dim3(1), dim3(SCANB_THREADS), 0, st, block_offsets, nb, total_dev, capacity);
     return hipGetLastError();
 }
 

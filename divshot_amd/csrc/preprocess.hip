@@ -10,6 +10,7 @@
 // Both kernels are HBM-streaming (236 B of parameters per splat, ~400 flop): one lane per splat.
 // The 45-float shN row (76 % of the bytes) is moved through LDS so that global traffic is
 // 16-B-per-lane coalesced while each lane still consumes / produces its own row.
+#include <cstdlib>
 #include "dvs_device.h"
 #include "dvs_kernels.h"
 
@@ -590,7 +591,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 // splat and view) and k_sh_grad_combine builds sh0 / shN from it afterwards — on one GPU right away, in data-parallel runs after the
 // all-gather of dcolor (the factorised exchange), with the same kernel. Per view the same expressions in the same order as
 // k_preprocess_bwd, so the geometry gradients of a batch are bit-identical to its views run one by one with opts.accumulate.
-template <bool ACCUM>
+template <bool ACCUM, bool NOHOIST>
 __global__ void __launch_bounds__(PP_BLOCK)
 k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read through dvs_load_cam() */, int n_views, int n,
                        const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
@@ -620,6 +621,10 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
     for (int view = 0; view < n_views; ++view) {
         const DvsCam cam = dvs_load_cam(view);
         const int64_t o = (int64_t)view * n + il;
+        // NOHOIST: keep the view-independent intermediates (exp of the scales, rotation, 3D covariance) from being hoisted out of the
+        // loop — they are cheap to recompute and would otherwise stay live across it
+        float s0_ = in_s0, s1_ = in_s1, s2_ = in_s2, q0_ = in_q.x, q1_ = in_q.y, q2_ = in_q.z, q3_ = in_q.w, op_ = in_op;
+        if (NOHOIST) asm volatile("" : "+v"(s0_), "+v"(s1_), "+v"(s2_), "+v"(q0_), "+v"(q1_), "+v"(q2_), "+v"(q3_), "+v"(op_));
         const int radius = valid ? radii[o] : 0;
         float gcol[3] = {0.f, 0.f, 0.f};
         if (radius > 0) {
@@ -664,7 +669,7 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
                 const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
                 gpv[0] += (gdir[0] - ux * ug) * inv_dl; gpv[1] += (gdir[1] - uy * ug) * inv_dl; gpv[2] += (gdir[2] - uz * ug) * inv_dl;
             }
-            a9_geometry(cam, px, py, pz, in_s0, in_s1, in_s2, in_q, in_op, fl, r0, r1, antialias, grad_mode, gpv, gscv, gqv, g_opv, dmv);
+            a9_geometry(cam, px, py, pz, s0_, s1_, s2_, make_float4(q0_, q1_, q2_, q3_), op_, fl, r0, r1, antialias, grad_mode, gpv, gscv, gqv, g_opv, dmv);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { gp[k] += gpv[k]; gsc[k] += gscv[k]; }
 #pragma unroll
@@ -888,12 +893,15 @@ hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, c
     if (n <= 0 || n_views <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = (size_t)PP_BLOCK * 6 * sizeof(float);
-#define DVS_PPV(A)                                                                                                              \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<A>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
+    static const bool nohoist = getenv("DVS_A9V_NOHOIST") && getenv("DVS_A9V_NOHOIST")[0] == '1';
+#define DVS_PPV1(A, N)                                                                                                          \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<A, N>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
                        deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_opacity, g_scale, g_rot,                         \
                        (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero, grad_mode)
+#define DVS_PPV(A) do { if (nohoist) DVS_PPV1(A, true); else DVS_PPV1(A, false); } while (0)
     if (accumulate) DVS_PPV(true); else DVS_PPV(false);
 #undef DVS_PPV
+#undef DVS_PPV1
     return hipGetLastError();
 }
 
