@@ -419,13 +419,15 @@ def main():
             dur_ms = in_step_ms if in_step_ms else single[dom]
             views_per_launch = G if in_step_ms else 1          # a launch inside the step composites all views of its group
             achieved = ab[dom] * views_per_launch / (dur_ms * 1e-3) / 1e9
-            traffic, traffic_src = None, None
+            traffic, traffic_src, same_run = None, None, False
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob
                 tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]      # the latest round's PMC passes
                 tj = json.load(open(tfile))
+                # the counters belong to the workload and batch shape they were collected on; any other run reports null
+                same_run = args.workload == tj.get("workload", "C3") and views_per_launch == tj.get("views_per_launch", 8)
                 for kname, rec_ in tj["kernels"].items():
-                    if kname.startswith("k_" + dom):
+                    if same_run and kname.startswith("k_" + dom):
                         traffic = rec_["hbm_bytes_per_launch_corrected"]
                         traffic_src = "profiles/" + os.path.basename(tfile) + " (2*FETCH_SIZE + WRITE_SIZE, KB->B)"
             except Exception:
@@ -448,7 +450,7 @@ def main():
                         insts = float(f[-1])
                     elif dur_us is None and len(f) > 6 and re.fullmatch(r"[0-9.]+", f[-10] or ""):
                         dur_us = float(f[-10])          # avg_us column of the kernel-trace table
-                if dur_us and act:
+                if dur_us and act and same_run:
                     valu = {"source": "profiles/" + os.path.basename(sq), "insts_valu_per_launch": insts, "active_quads_per_launch": act,
                             "avg_us_under_pmc": dur_us, "busy_fraction_at_2.4GHz": act * 4.0 / (1024 * dur_us * 1e-6 * 2.4e9)}
             except Exception:

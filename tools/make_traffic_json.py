@@ -29,7 +29,7 @@ def main():
            "reports half the bytes of wide coalesced reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibrated on "
            "k_preprocess_fwd (236 B read per splat). The factor 2 is NOT calibrated for the narrow gathers of the composite kernels "
            "(their figure is an upper bound), the counters include Infinity-Cache hits, and cross-XCD fp32 atomics are counted as writes.")
-    json.dump({"_how": how, "kernels": kernels}, sys.stdout, indent=1)
+    json.dump({"_how": how, "workload": "C3", "views_per_launch": 8, "kernels": kernels}, sys.stdout, indent=1)
     print()
 
 
