@@ -151,8 +151,8 @@ def main():
                     help="if > 0: this many views PER GPU per step instead of sharding --global-views (weak scaling, the round-1 shape)")
     ap.add_argument("--shn-tiled", type=int, default=1,
                     help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
-    ap.add_argument("--bwd-variant", default="reduce", choices=["blocks", "reduce", "mm"],
-                    help="A8 kernel (dvs_set_backward_variant): reduce = default (measured winner); blocks / mm = the measured alternatives")
+    ap.add_argument("--bwd-variant", default="blocks", choices=["blocks", "reduce", "mm"],
+                    help="A8 kernel (dvs_set_backward_variant): blocks = default (measured winner); reduce (round 1) / mm = the measured alternatives")
     ap.add_argument("--fwd-variant", default="quadrant", choices=["blocks", "quadrant"], help="A7 kernel (dvs_set_forward_variant)")
     ap.add_argument("--grad-mode", type=int, default=0, help="dvs_opts.grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (same cost)")
     ap.add_argument("--async-forward", type=int, default=1, help="1: dvs_set_async — the forward never synchronises the host (T stays on the device)")
@@ -419,6 +419,9 @@ def main():
             dur_ms = in_step_ms if in_step_ms else single[dom]
             views_per_launch = G if in_step_ms else 1          # a launch inside the step composites all views of its group
             achieved = ab[dom] * views_per_launch / (dur_ms * 1e-3) / 1e9
+            kern = "k_" + dom
+            if dom == "render_bwd":
+                kern = {"blocks": "k_render_bwd_blocks<", "reduce": "k_render_bwd<", "mm": "k_render_bwd_mm<"}[args.bwd_variant]
             traffic, traffic_src, same_run = None, None, False
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob
@@ -427,7 +430,7 @@ def main():
                 # the counters belong to the workload and batch shape they were collected on; any other run reports null
                 same_run = args.workload == tj.get("workload", "C3") and views_per_launch == tj.get("views_per_launch", 8)
                 for kname, rec_ in tj["kernels"].items():
-                    if same_run and kname.startswith("k_" + dom):
+                    if same_run and kname.startswith(kern):
                         traffic = rec_["hbm_bytes_per_launch_corrected"]
                         traffic_src = "profiles/" + os.path.basename(tfile) + " (2*FETCH_SIZE + WRITE_SIZE, KB->B)"
             except Exception:
@@ -441,7 +444,7 @@ def main():
                 sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")))[-1]
                 dur_us = act = insts = None
                 for line in open(sq):
-                    if not line.lstrip().startswith("k_" + dom):
+                    if not line.lstrip().startswith(kern):
                         continue
                     f = line.split()
                     if "SQ_ACTIVE_INST_VALU" in f:
@@ -455,7 +458,7 @@ def main():
                             "avg_us_under_pmc": dur_us, "busy_fraction_at_2.4GHz": act * 4.0 / (1024 * dur_us * 1e-6 * 2.4e9)}
             except Exception:
                 pass
-            roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": kern.rstrip("<"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": ab[dom] * views_per_launch, "views_per_launch": views_per_launch, "avg_launch_ms": dur_ms,
                         "avg_launch_ms_isolated": single[dom], "avg_launch_source": ("hipEvent pairs around the kernel inside a replica of the timed "

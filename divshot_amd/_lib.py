@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdvsraster.so")
+LIB_PATH = os.environ.get("DVS_RASTER_LIB") or os.path.join(_HERE, "lib", "libdvsraster.so")     # override: experiment builds (tools/)
 
 
 class DvsError(RuntimeError):

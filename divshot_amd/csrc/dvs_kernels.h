@@ -72,6 +72,6 @@ enum { DVS_FWD_BLOCKS = 0 /*per-4x4-block lists (experiment)*/, DVS_FWD_QUADRANT
 hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                         const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color,
                                         float* final_T, uint32_t* n_contrib);
-hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                        const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T,
+hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                        const uint32_t* sorted_splat, const float* splat2d, const float* bgs /*[n_views][3]*/, const float* final_T,
                                         const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode);

@@ -508,11 +508,6 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
-static ViewBg make_view_bg(int n_views, const float* bgs /*[n_views][3]*/) {
-    ViewBg b{};
-    for (int v = 0; v < n_views && v < DVS_MAX_VIEWS; ++v) for (int k = 0; k < 3; ++k) b.bg[v][k] = bgs[3 * v + k];
-    return b;
-}
 
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,

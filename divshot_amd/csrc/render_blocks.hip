@@ -31,14 +31,10 @@
 #include "dvs_kernels.h"
 #include "render_common.h"
 
-#define BK_RB 128                       // list entries staged per batch
-#ifndef BK_LDS_ACC
-#define BK_LDS_ACC 1                    // 1: group totals merged in an LDS table (ds_add_f32: measured LDS-bound, ~2 cycles per lane)
+#ifndef BK_RB
+#define BK_RB 64                        // list entries staged per batch (the four per-wave tables of A8 take 4 x BK_RB x 48 B)
 #endif
 #define BK_GPT (16 * BK_RB / RB)        // blocks tested per staging thread (two threads share an entry when BK_RB = 128)
-#ifndef BK_ACC_STRIDE
-#define BK_ACC_STRIDE 16                // floats per accumulator row (12 used)
-#endif
 #define BK_SW (BK_RB / 64)              // staging waves per block subset
 #define BK_ROWS (BK_GPT / 4)             // block rows per staging thread
 
@@ -240,17 +236,20 @@ __device__ __forceinline__ void group_reduce12(const float v[12], float q[3], in
 
 template <bool ABSGRAD>
 __global__ void __launch_bounds__(RB)
-k_render_bwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
-                    const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
-                    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
+k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
+                    int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
+                    const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
+                    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
                     float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage) {
     __shared__ BlockLds L;
-#if BK_LDS_ACC
-    __shared__ float s_acc[BK_RB * BK_ACC_STRIDE];          // per batch entry: the 12-float row, summed over the tile's pixels
-#endif
+    __shared__ float s_tab[4][BK_RB * 12];                  // per wave and batch entry: the 12-float row, summed over the wave's blocks
     __shared__ uint32_t s_blast[16];
-    const int tile = tile_of_block(blockIdx.x, num_tiles);
-    if (tile >= num_tiles) return;
+    (void)bg_arg;
+    const int tile_g = tile_of_block(blockIdx.x, num_tiles);
+    if (tile_g >= num_tiles) return;
+    const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
+    const float3 bgv = dvs_load_bg(view);
+    final_T += (size_t)view * W * H; n_contrib += (size_t)view * W * H; dL_dout += (size_t)view * 3 * W * H;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int block, lx, ly;
@@ -258,7 +257,7 @@ k_render_bwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
     const int px = tx * DVS_TILE + lx, py = ty * DVS_TILE + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
+    const uint2 range = ranges[tile_g];
     const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
     // which group total this lane publishes: column c = lane & 15 carries group c & 3; its four copies (c >> 2 = 0..3) take one
     // register each (the fourth idles); row r selects the value index inside the register (see group_reduce12)
@@ -266,21 +265,21 @@ k_render_bwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
     const int kv = lsel * 4 + ((lrow == 1) ? 2 : (lrow == 2) ? 1 : lrow);
     const bool publisher = lsel < 3 && kv < (ABSGRAD ? 11 : 9);
     const int xaddr = (lane ^ 32) << 2;
+    const int mygroup = lane & 3;
+    float* const tab = &s_tab[wave][kv];
 
     const float T_final = inside ? final_T[pix] : 0.f;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
     float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f;
     if (inside) { dLp0 = dL_dout[pix]; dLp1 = dL_dout[P + pix]; dLp2 = dL_dout[2 * P + pix]; }
-    const float bg_dot = (bg0 * dLp0 + bg1 * dLp1) + bg2 * dLp2;
+    const float bg_dot = (bgv.x * dLp0 + bgv.y * dLp1) + bgv.z * dLp2;
 
     // deepest contributor per block (lanes with equal lane & 3) and of the tile
     uint32_t bmax = last;
 #pragma unroll
     for (int d = 32; d >= 4; d >>= 1) bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, d, 64));
     if (lane < 4) s_blast[block] = bmax;
-#if BK_LDS_ACC
-    for (int e = threadIdx.x; e < BK_RB * BK_ACC_STRIDE; e += RB) s_acc[e] = 0.f;
-#endif
+    for (int e = threadIdx.x; e < 4 * BK_RB * 12; e += RB) (&s_tab[0][0])[e] = 0.f;
     __syncthreads();
     uint32_t todo = 0;
 #pragma unroll
@@ -298,7 +297,7 @@ k_render_bwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
         stage_blocks<true>(L, sorted_splat, range.x + base, cnt, base, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE), s_blast);
         __syncthreads();
         const int len = (int)L.cnt[block];
-        const int nmax = wave_max4(len);
+        const int nmax = __builtin_amdgcn_readfirstlane(wave_max4(len));
         int idx = len - 1;
         int jn = idx >= 0 ? (int)lp[idx] : 0;
 #pragma unroll 1
@@ -315,7 +314,7 @@ k_render_bwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
             const float oa = zo2.y * G;
             const float alpha = fminf(DVS_ALPHA_MAX, oa);
             const bool contrib = act && (k < last) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
-            if (!__any(contrib)) continue;
+            if (__builtin_amdgcn_ballot_w64(contrib) == 0) continue;
             const float4 cg = L.cog[j];
             const float3 c = make_float3(L.zoir[j].w, cg.w, L.bl[j]);
             const float al = contrib ? alpha : 0.f;
@@ -341,24 +340,27 @@ k_render_bwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
             float q[3];
             group_reduce12<ABSGRAD ? 11 : 9>(v, q, xaddr);
             const float val = lsel == 0 ? q[0] : (lsel == 1 ? q[1] : q[2]);
-#if BK_LDS_ACC
-            if (publisher && act && val != 0.f) atomicAdd(&s_acc[j * BK_ACC_STRIDE + kv], val);   // ds_add_f32: merges the groups and the four waves of the tile
-#else
-            if (publisher && act && val != 0.f) atomicAdd(&grow[(size_t)__float_as_uint(L.zoir[j].z) * 12 + kv], val);
-#endif
-        }
-#if BK_LDS_ACC
-        __syncthreads();
-        // one global atomic per touched (entry, value): consecutive threads add consecutive floats of a splat's 48-B row
-        for (int e = threadIdx.x; e < cnt * BK_ACC_STRIDE; e += RB) {
-            const float val = s_acc[e];
-            if (val != 0.f) {
-                const int ent = e / BK_ACC_STRIDE, comp = e % BK_ACC_STRIDE;
-                atomicAdd(&grow[(size_t)__float_as_uint(L.zoir[ent].z) * 12 + comp], val);
-                s_acc[e] = 0.f;
+            // The four groups hold (possibly equal) entries j: one group at a time reads, adds and writes its row of the wave's
+            // table. LDS operations of one wave execute in order, so a later group sees an earlier group's write — no float atomics
+            // (ds_add_f32 costs ~12 cycles per lane on gfx950). An idle group adds zeros to a stale row.
+            float* const slot = tab + j * 12;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (publisher && mygroup == g) *slot += val;
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
             }
         }
-#endif
+        __syncthreads();
+        // the tile's total per touched (entry, value): ONE global atomic each — consecutive threads add consecutive floats of a row
+        for (int e = threadIdx.x; e < cnt * 12; e += RB) {
+            const float val = (s_tab[0][e] + s_tab[1][e]) + (s_tab[2][e] + s_tab[3][e]);
+            if (val != 0.f) {
+                const int ent = e / 12, comp = e - 12 * ent;
+                atomicAdd(&grow[(size_t)__float_as_uint(L.zoir[ent].z) * 12 + comp], val);
+            }
+            s_tab[0][e] = 0.f; s_tab[1][e] = 0.f; s_tab[2][e] = 0.f; s_tab[3][e] = 0.f;
+        }
     }
 }
 
@@ -374,18 +376,18 @@ hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_
     return hipGetLastError();
 }
 
-hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
-                                        const uint32_t* sorted_splat, const float* splat2d, const float bg[3], const float* final_T,
+hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                        const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T,
                                         const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode) {
-    const int num_tiles = tiles_x * tiles_y;
+    const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
     const char* e_lds = getenv("DVS_BWD_EXTRA_LDS");
     const size_t extra_lds = e_lds ? (size_t)atoi(e_lds) : 0;
-#define DVS_RBB(KERNEL)                                                                                                          \
-    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, W, H, tiles_x, num_tiles, (const uint2*)ranges, sorted_splat, \
-                       (const float4*)splat2d, bg[0], bg[1], bg[2], final_T, n_contrib, dL_dout, grad_rows, lineage)
+#define DVS_RBB(KERNEL)                                                                                                             \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles, \
+                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, lineage)
     if (absgrad) DVS_RBB(k_render_bwd_blocks<true>); else DVS_RBB(k_render_bwd_blocks<false>);
 #undef DVS_RBB
     return hipGetLastError();

@@ -13,6 +13,12 @@ __device__ __forceinline__ float3 dvs_load_bg(int v) {
     return make_float3(f[0], f[1], f[2]);
 }
 
+static inline ViewBg make_view_bg(int n_views, const float* bgs /*[n_views][3]*/) {
+    ViewBg b{};
+    for (int v = 0; v < n_views && v < DVS_MAX_VIEWS; ++v) for (int k = 0; k < 3; ++k) b.bg[v][k] = bgs[3 * v + k];
+    return b;
+}
+
 // blockIdx -> tile: consecutive workgroups land on different XCDs (b % 8), so give each XCD a
 // contiguous band of tiles; neighbouring tiles share splats and therefore L2 lines.
 __device__ __forceinline__ int tile_of_block(int b, int num_tiles) {

@@ -227,11 +227,12 @@ int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
 
 /* The composite kernels exist in several variants with the same inputs and outputs, kept selectable so that the measured
  * comparison can be repeated (all of them pass the same parity tests). Backward (A8), results equal to fp32 roundoff:
- *   1 "reduce"  (default, the measured winner) per-8x8-quadrant cull masks, a 12-value wave-wide reduction tree per (wave, splat) visit
- *   0 "blocks"  per-4x4-pixel-block splat lists built while a batch is staged; the four 16-lane groups of a wave walk four different
- *               lists; group totals merged in LDS. Fewer vector instructions, but bound by the LDS float atomics (ds_add_f32)
+ *   0 "blocks"  (default, the measured winner since round 2) per-4x4-pixel-block splat lists built while a batch is staged; the four
+ *               16-lane groups of a wave walk four different lists; group totals go into a per-wave LDS table with plain
+ *               read-add-write, one group at a time; the four tables are summed and published once per (tile, splat, value)
+ *   1 "reduce"  (round 1) per-8x8-quadrant cull masks, a 12-value wave-wide reduction tree and one atomic row update per (wave, splat) visit
  *   2 "mm"      per-quadrant masks, the per-splat sums contracted on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); bound by its
- *               LDS footprint (3 workgroups per CU) and by the matrix and vector pipes not overlapping
+ *               LDS footprint (3 workgroups per CU) and by the matrix and vector pipes not overlapping; one view per launch only
  * Forward (A7), bit-identical results:  1 "quadrant" (default) / 0 "blocks".
  * The environment variables DVS_BWD_VARIANT / DVS_FWD_VARIANT (digits) set the defaults of new contexts. */
 int dvs_set_backward_variant(dvs_ctx* ctx, int variant);

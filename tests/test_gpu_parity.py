@@ -81,7 +81,7 @@ def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
             grads = rast.backward(dL, want_mean2d=True)
             torch.cuda.synchronize()
             runs[(mode, variant)] = ({k: v.cpu().numpy() for k, v in grads.items()}, rast.bwd_intermediates())
-    rast.set_backward_variant("reduce")
+    rast.set_backward_variant("blocks")
     rast._opts.grad_mode = 0
     return img_h, saved, keys, runs, (img_h - tgt) / tgt[0].size
 
@@ -610,8 +610,8 @@ def test_async_forward_no_host_sync(gpu_device):
     small.close(); small2.close()
 
 
-@pytest.mark.parametrize("tiled", [True, False])
-def test_multi_view_batch_equals_single_views(gpu_device, tiled):
+@pytest.mark.parametrize("tiled,bwd", [(True, "blocks"), (False, "blocks"), (True, "reduce")])
+def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     """dvs_raster_forward_views / _backward_views (BASELINE config C4: several cameras per iteration in ONE pass — parameters read once,
     one depth sort / scan / (view, tile) sort / composite launch, gradients written once) against the same views run one by one with
     opts.accumulate: images and every saved per-view array bit for bit (the per-view instance list is cut out of the batch-wide
@@ -627,6 +627,7 @@ def test_multi_view_batch_equals_single_views(gpu_device, tiled):
     tg = [torch.from_numpy(dv.synth_target(spec, i + 1)).cuda() for i in range(V)]
     single = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
     batch = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+    single.set_backward_variant("reduce"); batch.set_backward_variant(bwd)        # the batch's A8 kernel against the round-1 kernel, one view at a time
     Pd = params_to_device(P, single.tdev)
     if tiled:
         Pd = dict(Pd); Pd["shN"] = single.shn_relayout(Pd["shN"], n, to_tiled=True)
