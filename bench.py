@@ -155,6 +155,9 @@ def main():
                     help="A8 kernel (dvs_set_backward_variant): blocks = default (measured winner); reduce (round 1) / mm = the measured alternatives")
     ap.add_argument("--fwd-variant", default="quadrant", choices=["blocks", "quadrant"], help="A7 kernel (dvs_set_forward_variant)")
     ap.add_argument("--grad-mode", type=int, default=0, help="dvs_opts.grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (same cost)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture the step (one multi-view pass forward + loss gradient + backward) into a HIP graph after the warm-up and "
+                         "replay it (one GPU, --mode batch, asynchronous forward: the pass has no host synchronisation and fixed launch shapes)")
     ap.add_argument("--async-forward", type=int, default=1, help="1: dvs_set_async — the forward never synchronises the host (T stays on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
@@ -261,10 +264,11 @@ def main():
     torch.cuda.synchronize()
 
     def step(timed=False):
-        step_done.record(main_stream)              # everything enqueued so far (previous step incl. its exchange)
+        if n_ctx > 1:
+            step_done.record(main_stream)          # everything enqueued so far (previous step incl. its exchange)
         for gi in range(K):
             c = gi % n_ctx
-            st = streams[c]
+            st = streams[c] if n_ctx > 1 else torch.cuda.current_stream(dev)        # (one context: whatever stream is current — also a capturing one)
             with torch.cuda.stream(st):
                 if n_ctx > 1 and gi < n_ctx:
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
@@ -306,13 +310,25 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    run_step = step
+    graph = None
+    if args.graph:
+        if dist is not None or n_ctx > 1 or not args.async_forward:
+            raise SystemExit("bench.py: --graph needs one GPU, one context (--mode batch) and --async-forward 1")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run_step = lambda timed=False: graph.replay()
+        for _ in range(3):
+            run_step()
+        torch.cuda.synchronize()
     # one timing event per step boundary on the main stream (recorded, never waited on inside the loop): steps do not overlap, so
     # the deltas are the per-step durations; read after the timed region for the p10 / median / p90 spread
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i_ in range(args.steps):
         marks[i_].record(main_stream)
-        step(timed=True)
+        run_step(timed=True)
     marks[args.steps].record(main_stream)
     torch.cuda.synchronize()
     if dist is not None:
@@ -328,6 +344,32 @@ def main():
         r_.get_num_rendered()         # raises if an asynchronous forward of the timed region overflowed its instance arena
     grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
                                                                                    # (taken before the profiling iterations reuse the buffer)
+    # rccl-tests-style microbenchmark of the collectives the exchange is made of, at the exchange's sizes; outside the
+    # timed region, on scratch buffers. busbw uses the rccl-tests convention (all-reduce 2(N-1)/N, all-gather (N-1)/N of the total).
+    comm_micro = None
+    if dist is not None:
+        def _coll_ms(fn, iters=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            t_ = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        s_geom = torch.zeros_like(gbuf.flat_geom); s_flat = torch.zeros_like(gbuf.flat)
+        s_loc = torch.zeros((VPS * n * 3,), device=dev); s_all = torch.zeros((world * VPS * n * 3,), device=dev)
+        comm_micro = {}
+        for name, nbytes, fac, fn in (
+                ("all_reduce_geometry_44B_per_splat", s_geom.numel() * 4, 2.0 * (world - 1) / world, lambda: dist.all_reduce(s_geom)),
+                ("all_reduce_full_rows_236B_per_splat", s_flat.numel() * 4, 2.0 * (world - 1) / world, lambda: dist.all_reduce(s_flat)),
+                ("all_gather_dcolor_12B_per_splat_and_view", s_all.numel() * 4, (world - 1) / world, lambda: dist.all_gather_into_tensor(s_all, s_loc))):
+            ms_ = _coll_ms(fn)
+            comm_micro[name] = {"bytes": nbytes, "ms": ms_, "algbw_GBps": nbytes / ms_ / 1e6, "busbw_GBps": fac * nbytes / ms_ / 1e6}
+        del s_geom, s_flat, s_loc, s_all
     # everything below measures ONE view at a time: its own single-view context (the step's contexts are sized and primed for groups)
     rast1 = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
     rast1.set_backward_variant(args.bwd_variant); rast1.set_forward_variant(args.fwd_variant); rast1.set_async(bool(args.async_forward))
@@ -479,7 +521,7 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "strict_single_view": strict, "t_raster_ms_per_step": (ms_per_step - comm_ms["mean"]) if comm_ms else ms_per_step,
-            "t_comm_exposed_ms_per_step": comm_ms, "clocks": clocks,
+            "t_comm_exposed_ms_per_step": comm_ms, "comm_microbench": comm_micro, "clocks": clocks,
             "step_ms_p10_p50_p90": step_spread,
             "device": device_info,
             "dtype": "f32", "data": "synthetic",
@@ -488,7 +530,7 @@ def main():
                                    + (f" as {K} multi-view pass(es) of {G} view(s) (dvs_raster_forward_views / dvs_raster_backward_*)"
                                       + (" software-pipelined over two contexts/streams, gradients accumulated" if K > 1 else ""))
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "groups": K, "views_per_group": G, "async_forward": bool(args.async_forward), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "groups": K, "views_per_group": G, "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,

@@ -40,9 +40,9 @@
 
 struct __attribute__((aligned(16))) BlockLds {
     float4 xyc[BK_RB];            // mean x, mean y, cs.x, cs.y        (cs = exponent constants, see render.hip)
-    float4 zoir[BK_RB];           // cs.z, opacity, splat id bits, colour r
+    float4 zoir[BK_RB];           // cs.z, opacity, colour b, colour r
     float4 cog[BK_RB];            // conic a, b, c, colour g
-    float bl[BK_RB];              // colour b
+    uint32_t id[BK_RB];           // splat id (row of the gradient table)
     uint8_t list[16][BK_RB];      // per block: batch indices of the entries that can reach it, in list order
     uint32_t cnt[16];             // list lengths
     uint32_t wcnt[BK_SW][16];     // per staging wave
@@ -63,9 +63,9 @@ __device__ __forceinline__ void stage_blocks(BlockLds& L, const uint32_t* __rest
         const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
         if (sub == 0) {
             L.xyc[e] = make_float4(r0.x, r0.y, -0.72134752044448170f * a, -1.4426950408889634f * b);
-            L.zoir[e] = make_float4(-0.72134752044448170f * c, op, __uint_as_float(id), r1.z);
+            L.zoir[e] = make_float4(-0.72134752044448170f * c, op, bl, r1.z);
             L.cog[e] = make_float4(a, b, c, r1.w);
-            L.bl[e] = bl;
+            L.id[e] = id;
         }
         // alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o). The minimum of the convex form over a block's
         // pixel rectangle is 0 if the mean lies inside, otherwise it lies on an edge FACING the mean: at most one vertical edge (the
@@ -192,7 +192,7 @@ k_render_fwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
             const bool take = valid && !stop;
             done = done || stop;
             const float w = take ? aT : 0.f;
-            C0 = __builtin_fmaf(zo.w, w, C0); C1 = __builtin_fmaf(L.cog[j].w, w, C1); C2 = __builtin_fmaf(L.bl[j], w, C2);
+            C0 = __builtin_fmaf(zo.w, w, C0); C1 = __builtin_fmaf(L.cog[j].w, w, C1); C2 = __builtin_fmaf(zo.z, w, C2);
             T = T - w;
             last = take ? (uint32_t)(base + j + 1) : last;
             if ((it & 15) == 15 && __all(done)) break;
@@ -307,7 +307,8 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             jn = idx >= 1 ? (int)lp[idx - 1] : 0;
             const uint32_t k = (uint32_t)(base + j);
             const float4 xy = L.xyc[j];
-            const float2 zo2 = *reinterpret_cast<const float2*>(&L.zoir[j]);
+            const float4 zo4 = L.zoir[j];
+            const float2 zo2 = make_float2(zo4.x, zo4.y);
             const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float p2 = __builtin_fmaf(zo2.x * dy, dy, __builtin_fmaf(xy.w, dy, xy.z * dx) * dx);   // same expression as the forward
             const float G = __builtin_amdgcn_exp2f(p2);
@@ -316,7 +317,7 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             const bool contrib = act && (k < last) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
             if (__builtin_amdgcn_ballot_w64(contrib) == 0) continue;
             const float4 cg = L.cog[j];
-            const float3 c = make_float3(L.zoir[j].w, cg.w, L.bl[j]);
+            const float3 c = make_float3(zo4.w, cg.w, zo4.z);
             const float al = contrib ? alpha : 0.f;
             const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);
             T = T * inv_1ma;
@@ -343,7 +344,7 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             // The four groups hold (possibly equal) entries j: one group at a time reads, adds and writes its row of the wave's
             // table. LDS operations of one wave execute in order, so a later group sees an earlier group's write — no float atomics
             // (ds_add_f32 costs ~12 cycles per lane on gfx950). An idle group adds zeros to a stale row.
-            float* const slot = tab + j * 12;
+            float* const slot = reinterpret_cast<float*>(reinterpret_cast<char*>(tab) + __umul24((unsigned)j, 48u));
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (publisher && mygroup == g) *slot += val;
@@ -357,7 +358,7 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             const float val = (s_tab[0][e] + s_tab[1][e]) + (s_tab[2][e] + s_tab[3][e]);
             if (val != 0.f) {
                 const int ent = e / 12, comp = e - 12 * ent;
-                atomicAdd(&grow[(size_t)__float_as_uint(L.zoir[ent].z) * 12 + comp], val);
+                atomicAdd(&grow[(size_t)L.id[ent] * 12 + comp], val);
             }
             s_tab[0][e] = 0.f; s_tab[1][e] = 0.f; s_tab[2][e] = 0.f; s_tab[3][e] = 0.f;
         }

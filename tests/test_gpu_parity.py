@@ -610,6 +610,52 @@ def test_async_forward_no_host_sync(gpu_device):
     small.close(); small2.close()
 
 
+def test_hip_graph_replay_of_the_pass(gpu_device):
+    """The asynchronous multi-view pass has no host synchronisation and fixed launch shapes, so a whole training-iteration pass
+    (forward of two views, loss gradient, backward) can be captured into a HIP graph and replayed: after the parameters change, a
+    replay gives the same images and gradients as the eager pass on the new parameters, and the instance count is still reported."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H, V = 20_000, 320, 240, 2
+    spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=4, seed=9)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, i) for i in range(V)]
+    tg = torch.stack([torch.from_numpy(dv.synth_target(spec, i)) for i in range(V)]).cuda()
+    r = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+    r.set_async(True)
+    Pd = params_to_device(P, r.tdev)
+    Pd["shN"] = r.shn_relayout(Pd["shN"], n, to_tiled=True)
+    out = torch.empty((V, 3, H, W), device=r.tdev)
+    grads = {k: torch.zeros_like(v) for k, v in Pd.items()}
+    def one_pass():
+        imgs = r.forward_views(Pd, cams, sh_degree=3, absgrad=True, out=out, shn_tiled=True)
+        dL = (imgs - tg) * (1.0 / (W * H))
+        r.backward_views(dL, grads=grads)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):                                     # warm-up: the arena reaches its steady size, T of earlier passes is known
+            one_pass()
+    torch.cuda.synchronize()
+    T0 = r.get_num_rendered()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        one_pass()
+    Pd["pos"] += 0.01 * torch.randn_like(Pd["pos"])            # in place: the graph holds the pointers
+    Pd["opacity"] += 0.1
+    graph.replay()
+    torch.cuda.synchronize()
+    T1 = r.get_num_rendered()
+    img_g = out.clone(); g_g = {k: v.clone() for k, v in grads.items()}
+    one_pass()
+    torch.cuda.synchronize()
+    assert r.get_num_rendered() == T1 and T1 != T0
+    assert torch.equal(out, img_g)
+    for k in KEYS:
+        m, worst = rel_close(g_g[k].cpu().numpy(), grads[k].cpu().numpy(), 1e-4, 2e-6)
+        assert m.all(), (k, worst)
+    r.close()
+
+
 @pytest.mark.parametrize("tiled,bwd", [(True, "blocks"), (False, "blocks"), (True, "reduce")])
 def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     """dvs_raster_forward_views / _backward_views (BASELINE config C4: several cameras per iteration in ONE pass — parameters read once,
