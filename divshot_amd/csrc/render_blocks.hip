@@ -1,4 +1,5 @@
-// render_blocks.hip — A7 / A8 with per-4x4-block splat lists ("blocks" variant: a measured experiment, NOT the default — see the end of this header).
+// render_blocks.hip — A7 / A8 with per-4x4-block splat lists. The A8 kernel here is the DEFAULT composite backward (since round 2);
+// the A7 kernel is a measured experiment (not faster than render.hip's, see the end of this header).
 //
 // The round-1 composite kernels walk, per 8x8 quadrant (= one wave), every splat whose alpha >= 1/255 ellipse reaches the quadrant;
 // on the bench scene a visit has 21 of 64 lanes contributing (a footprint of ~40 px inside the tile against a 64-px quadrant), and
@@ -7,25 +8,30 @@
 // tile's sixteen blocks and the survivors are compacted, by ballot + mbcnt, into sixteen per-block index lists. A wave still owns an
 // 8x8 quadrant, but its 64 lanes form FOUR interleaved groups of 16 (group = lane & 3 = one 4x4 block) and every group walks its own
 // list with its own cursor: in one iteration the four groups evaluate four different splats. A wave needs max(list length of its
-// four blocks) iterations instead of one per quadrant visit: 0.62x the iterations at 53 % lane utilisation (measured on the bench
-// scene from the oracle's lists), and the scalar bit-walk of the round-1 forward is gone (the cursor is a vector register).
+// four blocks) iterations instead of one per quadrant visit (0.74x the iterations at 44 % lane utilisation with batches of 64), and
+// the scalar bit-walk of the round-1 forward is gone (the cursor is a vector register).
 //
 // Backward: the 12 per-pixel partials are still reduced across lanes, but only over a group (lanes with equal lane & 3): the two
 // packing swaps (v_permlane32_swap, v_permlane16_swap) fold the four 16-lane rows, two ds_swizzle steps (xor 4, xor 8) finish —
-// two butterfly levels fewer than the wave-wide tree. Group totals are added (ds_add_f32) into a per-batch-entry LDS table, which
-// also merges the four waves of the tile; after the batch each touched entry is published with ONE global fp32 atomic per value:
-// T x 11 atomics per view instead of (quadrant visits) x 11, i.e. about half the cross-XCD atomic traffic of the round-1 kernel.
+// two butterfly levels fewer than the wave-wide tree, and one tree serves four (splat, block) pairs. The group totals then have to
+// be merged per splat — across the groups of a wave, which may or may not hold the same entry in an iteration, and across the four
+// waves. gfx950 has no cheap float merge primitive (measured below), so the merge stays inside the wave: each wave owns a table
+// [batch entry][12 floats] in LDS and the four groups add their totals with plain ds_read / v_add / ds_write, one group after the
+// other — the LDS executes the operations of a wave in program order, so two groups holding the same entry are safe without
+// atomics. After the batch the four tables are summed and each touched (entry, value) is published with ONE global fp32 atomic:
+// T x 11 atomics per view instead of (quadrant visits) x 11, about half the cross-XCD atomic traffic of the round-1 kernel.
+// Batches of 64 entries keep the tables at 12 KB (8 workgroups per CU; with 128 the kernel loses 30 % to occupancy).
 //
 // Same inputs, same 48-B row contract (moments about the mean), same alpha rule and thresholds as render.hip; selected by
 // dvs_set_backward_variant / dvs_set_forward_variant (DVS_*_BLOCKS). Reference anchors as in render.hip.
 //
-// MEASURED (C3, 1 MI355X, profiles/r02_variants.md): correct (all parity tests, forward bit-identical) but not faster.
-//   forward  0.22 ms vs 0.18 ms: 0.62x the iterations, but 39 instead of 28 vector instructions per iteration (per-lane cursor and
+// MEASURED (C3, 1 MI355X, profiles/r02_variants.md):
+//   backward 0.46-0.48 ms per view against 0.51 ms (round-1 kernel, same box); inside the 8-view launch 3.35 vs 3.90 ms.
+//            Earlier forms of the merge: ds_add_f32 into one table per tile 0.83 ms (the LDS float atomic costs ~12 cycles per
+//            active lane, tools/ubench/lds_atomic.hip: the LDS was busy 100 % of the kernel); global atomics per group 1.60 ms.
+//            Ranking the sixteen lists by length per batch and dealing them to the waves in that order: -1.3 % instructions only.
+//   forward  0.22 ms vs 0.18 ms: fewer iterations, but 39 instead of 28 vector instructions per iteration (per-lane cursor and
 //            addresses) plus the sixteen block tests and the list compaction per staged entry (+25 M instructions): same total.
-//   backward 0.83 ms vs 0.50 ms: vector instructions fall from 335 M to 260 M, but merging the group totals is the wall — ds_add_f32
-//            costs ~12 cycles per active lane on gfx950 (tools/ubench/lds_atomic.hip: 528 cycles for 44 lanes; it is not a native
-//            LDS-ALU operation), so the LDS is busy 100 % of the kernel; publishing each group with global atomics instead
-//            (BK_LDS_ACC 0: four rows per instruction, 2.3x the row updates of the round-1 kernel) measured 1.60 ms.
 #include <cstdlib>
 #include "dvs_device.h"
 #include "dvs_kernels.h"
