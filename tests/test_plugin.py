@@ -154,24 +154,28 @@ def test_cli_adc_without_absgrad(tmp_path):
 @pytest.mark.gpu
 def test_cli_rccl_single_rank(tmp_path):
     """The plugin's data-parallel path (include/dvs_comm.h, librccl opened from C++) on the one GPU this box has: DVS_FORCE_COMM=1 runs
-    the gradient all-reduce and the statistics all-reduces of every step on a 1-rank RCCL communicator (the identity), so the run
-    must behave like the plain one: same refinement schedule and splat counts, same loss level."""
+    the gradient exchange — both forms: factorised (all-gather of the colour gradients, all-reduce of the geometry groups, SH rows
+    rebuilt with dvs_sh_grad_combine) and one all-reduce of all rows — and the statistics all-reduces of every step on a 1-rank RCCL
+    communicator (the identity), so the runs must behave like the plain one: same refinement schedule and splat counts, same loss level."""
     import socket
     spec = ["--inputPath", "synthetic:N=20000,W=256,H=192,cams=4,sh=1,seed=7", "--maxIteration", "350", "--warmupLength", "100",
             "--refineEvery", "100", "--refineStopIter", "320", "--densifyStrategy", "1"]
     runs = []
-    for force in ("0", "1"):
+    for force, exch in (("0", "factorised"), ("1", "factorised"), ("1", "allreduce")):
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
-        env = dict(os.environ, DVS_FORCE_COMM=force, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        p = subprocess.run([DRIVER] + spec + ["--outputPath", str(tmp_path / ("m" + force) / "iteration")], capture_output=True, text=True,
+        env = dict(os.environ, DVS_FORCE_COMM=force, DVS_EXCHANGE=exch, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        p = subprocess.run([DRIVER] + spec + ["--outputPath", str(tmp_path / ("m" + force + exch) / "iteration")], capture_output=True, text=True,
                            timeout=600, env=env)
         assert p.returncode == 0, p.stdout + p.stderr
         counts = [int(m.group(3)) for m in re.finditer(r"mcmc @(\d+): (\d+) -> (\d+) splats", p.stderr)]
         losses = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+)", p.stderr)]
         runs.append((counts, losses, p.stderr))
-    assert "RCCL communicator up" in runs[1][2] and "RCCL communicator up" not in runs[0][2]
-    assert runs[0][0] == runs[1][0] and len(runs[0][0]) == 2
-    assert abs(runs[0][1][-1] - runs[1][1][-1]) < 0.05 * runs[0][1][-1], (runs[0][1], runs[1][1])
+    assert "RCCL communicator up" not in runs[0][2]
+    assert "gradient exchange: factorised" in runs[1][2] and "gradient exchange: all-reduce of all rows" in runs[2][2]
+    for k in (1, 2):
+        assert runs[0][0] == runs[k][0] and len(runs[0][0]) == 2
+        assert abs(runs[0][1][-1] - runs[k][1][-1]) < 0.05 * runs[0][1][-1], (runs[0][1], runs[k][1])
 
 
 @pytest.mark.gpu
