@@ -83,11 +83,8 @@ k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n_host, const uint64_t* 
             const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
             const bool valid = idx < n;
             const uint32_t d = valid ? ((kreg[r] >> shift) & dmask) : 0u;
-            const uint64_t peers = match_digit(d, valid);
-            if (valid) {
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-                if (below == 0) cnt[wave][d] += (uint32_t)__popcll(peers);
-            }
+            // integer LDS atomics are native (unlike ds_add_f32): one ds_add_u32 per key into the wave's own counters
+            if (valid) atomicAdd(&cnt[wave][d], 1u);
         }
         __syncthreads();
         const uint32_t d = threadIdx.x;
