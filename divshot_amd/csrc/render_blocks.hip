@@ -370,11 +370,12 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             const float val = lsel == 0 ? q[0] : (lsel == 1 ? q[1] : q[2]);
             // The four groups hold (possibly equal) entries j: one group at a time reads, adds and writes its row of the wave's
             // table. LDS operations of one wave execute in order, so a later group sees an earlier group's write — no float atomics
-            // (ds_add_f32 costs ~12 cycles per lane on gfx950). An idle group adds zeros to a stale row.
+            // (ds_add_f32 costs ~12 cycles per lane on gfx950). A group whose list is exhausted holds a stale entry: it stays out.
             float* const slot = reinterpret_cast<float*>(reinterpret_cast<char*>(tab) + __umul24((unsigned)j, 48u));
+            const bool pub = publisher && act;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (publisher && mygroup == g) *slot += val;
+                if (pub && mygroup == g) *slot += val;
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("" ::: "memory");
             }
