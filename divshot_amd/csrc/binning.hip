@@ -253,35 +253,35 @@ k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __r
 __global__ void __launch_bounds__(SCANB_THREADS)
 k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint64_t* __restrict__ total /*[0] = T, [1] += (T > capacity)*/,
                    uint64_t capacity) {
-    // one workgroup of 1024 threads, one round: thread t owns a contiguous chunk of the block sums, sums it, the chunk sums are scanned
-    // once (16 waves), then the chunk is rewritten as exclusive offsets. (A multi-view batch has 31 k block sums: 31 per thread.)
-    __shared__ uint32_t tmp[SCANB_THREADS / 64];
-    const uint32_t per = (num_blocks + SCANB_THREADS - 1) / SCANB_THREADS;
-    const uint32_t lo = threadIdx.x * per, hi = min(num_blocks, lo + per);
-    __shared__ unsigned long long wide;                  // the true 64-bit total: T >= 2^32 or > capacity is an error (offsets are 32-bit)
-    if (threadIdx.x == 0) wide = 0ull;
-    uint32_t s = 0;
+    // One workgroup of 16 waves (a multi-view batch has 31 k block sums). Wave w owns a contiguous segment, read in rows of 64
+    // consecutive values (coalesced): first the segment totals, scanned over the waves, then every row is scanned across the lanes
+    // and rewritten as exclusive offsets with a running carry. (Round 2a gave each THREAD a contiguous chunk: stride-31 accesses, 47 us.)
+    __shared__ unsigned long long wsum[SCANB_THREADS / 64];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t rows_per_wave = (num_blocks + SCANB_THREADS - 1) / SCANB_THREADS;      // rows of 64 per wave
+    const uint32_t seg = wave * rows_per_wave * 64u;
     unsigned long long s64 = 0ull;
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = block_sums[i]; s += v; s64 += v; }
-    // exclusive scan of one value per thread over the 16 waves (contains the __syncthreads that publish `wide = 0`)
-    uint32_t run;
-    {
-        const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-        uint32_t inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
-        if (lane == 63) tmp[wave] = inc;
-        __syncthreads();
-        uint32_t wbase = 0;
-#pragma unroll
-        for (int w = 0; w < SCANB_THREADS / 64; ++w) { const uint32_t t = tmp[w]; if ((uint32_t)w < wave) wbase += t; }
-        run = wbase + inc - s;
+    for (uint32_t r = 0; r < rows_per_wave; ++r) {
+        const uint32_t i = seg + r * 64u + lane;
+        s64 += i < num_blocks ? block_sums[i] : 0u;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s64 += __shfl_xor(s64, d, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&wide, s64);
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (lane == 0) wsum[wave] = s64;
     __syncthreads();
+    unsigned long long base64 = 0ull, wide = 0ull;        // the true 64-bit total: T >= 2^32 or > capacity is an error (offsets are 32-bit)
+#pragma unroll
+    for (int w = 0; w < SCANB_THREADS / 64; ++w) { const unsigned long long t = wsum[w]; if ((uint32_t)w < wave) base64 += t; wide += t; }
+    uint32_t carry = (uint32_t)base64;
+    for (uint32_t r = 0; r < rows_per_wave; ++r) {
+        const uint32_t i = seg + r * 64u + lane;
+        const uint32_t v = i < num_blocks ? block_sums[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+        if (i < num_blocks) block_sums[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
     if (threadIdx.x == 0) { total[0] = wide; if (wide > capacity) total[1] += 1ull; }
 }
 
@@ -360,10 +360,27 @@ hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_id
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_tile_ranges(uint64_t T_host, const uint64_t* __restrict__ T_dev, const uint32_t* __restrict__ sorted_tile, uint2* __restrict__ ranges) {
     const uint64_t T = T_dev ? (*T_dev < T_host ? *T_dev : T_host) : T_host;
-    for (uint64_t j = (uint64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; j < T; j += (uint64_t)gridDim.x * SORT_BLOCK) {
-        const uint32_t t = sorted_tile[j];
-        if (j == 0 || sorted_tile[j - 1] != t) ranges[t].x = (uint32_t)j;
-        if (j + 1 == T || sorted_tile[j + 1] != t) ranges[t].y = (uint32_t)(j + 1);
+    // four consecutive instances per thread (one 16-B load + the two neighbours)
+    for (uint64_t q = (uint64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; q * 4 < T; q += (uint64_t)gridDim.x * SORT_BLOCK) {
+        const uint64_t j0 = q * 4;
+        uint32_t t[6];                                  // t[0] = element j0 - 1, t[1..4] = j0 .. j0 + 3, t[5] = j0 + 4
+        if (j0 + 4 <= T) {
+            const uint4 v = reinterpret_cast<const uint4*>(sorted_tile)[q];
+            t[1] = v.x; t[2] = v.y; t[3] = v.z; t[4] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[1 + k] = j0 + k < T ? sorted_tile[j0 + k] : 0xFFFFFFFFu;
+        }
+        t[0] = j0 > 0 ? sorted_tile[j0 - 1] : 0xFFFFFFFFu;
+        t[5] = j0 + 4 < T ? sorted_tile[j0 + 4] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t j = j0 + k;
+            if (j < T) {
+                if (j == 0 || t[k] != t[k + 1]) ranges[t[k + 1]].x = (uint32_t)j;
+                if (j + 1 == T || t[k + 2] != t[k + 1]) ranges[t[k + 1]].y = (uint32_t)(j + 1);
+            }
+        }
     }
 }
 
@@ -373,7 +390,7 @@ hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* so
     if (e != hipSuccess) return e;
     if (T == 0) return hipSuccess;
     const uint64_t T_grid = (T_dev && T_expected > 0 && T_expected < T) ? T_expected : T;
-    const uint32_t nb = (uint32_t)((T_grid + SORT_BLOCK - 1) / SORT_BLOCK);
+    const uint32_t nb = (uint32_t)((T_grid + 4 * SORT_BLOCK - 1) / (4 * SORT_BLOCK));
     hipLaunchKernelGGL(k_tile_ranges, dim3(nb), dim3(SORT_BLOCK), 0, st, T, T_dev, sorted_tile, (uint2*)ranges);
     return hipGetLastError();
 }
