@@ -142,6 +142,9 @@ def main():
                          "parameters read once, one sort / scan / composite launch per step); grouped: --groups passes pipelined over two "
                          "contexts / streams; pipelined: one view per pass (the round-1 shape)")
     ap.add_argument("--groups", type=int, default=2, help="grouped mode: multi-view groups per rank and step")
+    ap.add_argument("--stagger", type=int, default=0,
+                    help="grouped / pipelined: 1 = a group's forward starts only when the previous group's forward has been composited, so that "
+                         "its HBM-bound front end runs under the previous group's VALU-bound backward instead of beside its front end")
     ap.add_argument("--contexts", type=int, default=2, help="rasterizer contexts / HIP streams the groups of a step are pipelined over")
     ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
                     help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
@@ -155,6 +158,9 @@ def main():
                     help="A8 kernel (dvs_set_backward_variant): blocks = default (measured winner); reduce (round 1) / mm = the measured alternatives")
     ap.add_argument("--fwd-variant", default="quadrant", choices=["blocks", "quadrant"], help="A7 kernel (dvs_set_forward_variant)")
     ap.add_argument("--grad-mode", type=int, default=0, help="dvs_opts.grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (same cost)")
+    ap.add_argument("--early-gather", type=int, default=1,
+                    help="N>1, factorised exchange, --mode batch: 1 = the colour gradients are taken from the composite backward's rows "
+                         "(dvs_raster_backward_dcolor) and their all-gather runs under the preprocess backward (A9)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture the step (one multi-view pass forward + loss gradient + backward) into a HIP graph after the warm-up and "
                          "replay it (one GPU, --mode batch, asynchronous forward: the pass has no host synchronisation and fixed launch shapes)")
@@ -180,9 +186,10 @@ def main():
     dev_index = local_rank % ndev          # (a functional test may oversubscribe one GPU with a gloo group; normally 1 rank = 1 GPU)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or os.environ.get("DVS_FORCE_COLLECTIVES") == "1":     # (forced: the N>1 step over a 1-rank communicator — a hardware test of the path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         backend = os.environ.get("DVS_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -251,13 +258,18 @@ def main():
         # (w-1) 12 G + ring 44 < ring 236 for every world size.
         exchange = "factorised"
     factorised = dist is not None and exchange == "factorised"
+    early = factorised and bool(args.early_gather) and K == 1
     if factorised:
-        fx = FactorisedExchange(n, dev, world, views_per_rank=VPS)
+        fx = FactorisedExchange(n, dev, world, views_per_rank=VPS, rank_major=early)
+        dcolor_scratch = torch.empty((VPS, n, 3), dtype=torch.float32, device=dev) if early else None
         campos_all = np.array([list(dv.synth_camera(spec, views_of(r)[v]).campos) for r, v in fx.slots()], np.float32)
         # rebuild the SH rows of a view's slots right behind its all-gather, on the exchange's side stream
-        fx.set_combiner(lambda lo, hi, acc: rast.sh_grad_combine(params["pos"], campos_all[lo:hi], fx.dcolor_all[lo:hi], gbuf.views["sh0"],
-                                                                 gbuf.views["shN"], deg, accumulate=acc, shn_tiled=tiled))
+        if not early:
+            fx.set_combiner(lambda lo, hi, acc: rast.sh_grad_combine(params["pos"], campos_all[lo:hi], fx.dcolor_all[lo:hi], gbuf.views["sh0"],
+                                                                     gbuf.views["shN"], deg, accumulate=acc, shn_tiled=tiled))
+    dcol_done = torch.cuda.Event()
     bwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
+    fwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
     step_done = torch.cuda.Event()
     main_stream = torch.cuda.current_stream(dev)
     comm_marks = []                               # (event before the exposed exchange, event after it) per timed step
@@ -272,15 +284,23 @@ def main():
             with torch.cuda.stream(st):
                 if n_ctx > 1 and gi < n_ctx:
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
+                if n_ctx > 1 and args.stagger and gi > 0:
+                    st.wait_event(fwd_done[(gi - 1) % n_ctx])
                 imgs = rasts[c].forward_views(params, cams_group[gi], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled,
                                               grad_mode=args.grad_mode)
+                if n_ctx > 1:
+                    fwd_done[c].record(st)
                 dL = torch.add(neg_targets_group[gi], imgs, alpha=inv_P)
                 g = grads
                 if factorised:
-                    g = dict(grads); g["dcolor"] = fx.dcolor_local[gi * G:(gi + 1) * G]
+                    g = dict(grads); g["dcolor"] = dcolor_scratch if early else fx.dcolor_local[gi * G:(gi + 1) * G]
                 # A8 (composite backward) writes only this context's intermediate rows: it needs no ordering against the other
                 # group. Only A9, which accumulates into the shared gradient rows non-atomically, runs in group order.
                 rasts[c].backward_composite(dL)
+                if early:          # the colour gradients leave before A9: their all-gather runs under it, on the exchange's side stream
+                    rasts[c].backward_dcolor(fx.dcolor_local)
+                    dcol_done.record(st)
+                    fx.gather_all(dcol_done)
                 if n_ctx > 1 and gi > 0:
                     st.wait_event(bwd_done[(gi - 1) % n_ctx])
                 rasts[c].backward_project(grads=g, accumulate=(gi > 0), factorised_sh=factorised)
@@ -530,7 +550,7 @@ def main():
                                    + (f" as {K} multi-view pass(es) of {G} view(s) (dvs_raster_forward_views / dvs_raster_backward_*)"
                                       + (" software-pipelined over two contexts/streams, gradients accumulated" if K > 1 else ""))
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "groups": K, "views_per_group": G, "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "stagger": bool(args.stagger), "groups": K, "views_per_group": G, "early_gather": bool(early), "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,

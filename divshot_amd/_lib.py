@@ -81,6 +81,7 @@ _PROTOS = {
     "dvs_raster_backward_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Opts), C.c_void_p]),
     "dvs_raster_backward_project": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.c_void_p, C.POINTER(Opts),
                                               C.POINTER(SplatGrads)]),
+    "dvs_raster_backward_dcolor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_sh_grad_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]),
     "dvs_shn_relayout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -560,6 +560,15 @@ int dvs_sh_grad_combine(dvs_ctx* c, void* stream, int n, const float* pos, int s
     return DVS_OK;
 }
 
+int dvs_raster_backward_dcolor(dvs_ctx* c, void* stream, float* dcolor) {
+    if (!c || !dcolor || ((uintptr_t)dcolor & 15u)) { g_last_error = "dvs_raster_backward_dcolor: bad argument (dcolor: 16-byte aligned device array)"; return DVS_ERR_INVALID; }
+    if (!c->rows_pending) { g_last_error = "dvs_raster_backward_dcolor: no dvs_raster_backward_composite pending on this context"; return DVS_ERR_STATE; }
+    HIPCHECK(hipSetDevice(c->device));
+    const dvs_fwd_state& s = c->st;
+    HIPCHECK(dvs_launch_dcolor_from_rows((hipStream_t)stream, (int64_t)c->n_views * s.n, s.radii, s.flags, c->g_rows.as<float>(), dcolor));
+    return DVS_OK;
+}
+
 int dvs_set_async(dvs_ctx* c, int enable) {
     if (!c) { g_last_error = "dvs_set_async: null context"; return DVS_ERR_INVALID; }
     c->async_T = enable != 0;

@@ -27,6 +27,7 @@ hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, c
 hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
                                       const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled);
 // reference rows [n][45] <-> tiled [ceil(n/64)][45][64]
+hipError_t dvs_launch_dcolor_from_rows(hipStream_t st, int64_t total, const int* radii, const uint32_t* flags, const float* rows, float* dcolor);
 hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, float* dst, int to_tiled);
 
 // binning.hip

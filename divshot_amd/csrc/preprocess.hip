@@ -925,6 +925,36 @@ hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, i
     return hipGetLastError();
 }
 
+// ---- colour gradients straight from the A8 rows (before A9) ----------------------------------------------------------------
+// dcolor[o] = dL/d(colour) of (view, splat) o with the clamped channels masked — exactly what A9 emits — so that a data-parallel
+// trainer can start the all-gather of the colour gradients while A9 is still running.
+__global__ void __launch_bounds__(PP_BLOCK)
+k_dcolor_from_rows(int64_t total, const int* __restrict__ radii, const uint32_t* __restrict__ flags, const float4* __restrict__ rows,
+                   float* __restrict__ dcolor) {
+    __shared__ float l_col[PP_BLOCK * 3];
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int64_t o = base + threadIdx.x;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (o < total && radii[o] > 0) {
+        const float4 r1 = rows[3 * o + 1];
+        const float r2x = rows[3 * o + 2].x;
+        const uint32_t fl = flags[o];
+        g[0] = (fl & 1u) ? 0.f : r1.z; g[1] = (fl & 2u) ? 0.f : r1.w; g[2] = (fl & 4u) ? 0.f : r2x;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) l_col[threadIdx.x * 3 + k] = g[k];
+    __syncthreads();
+    const int64_t lim = (total - base) * 3;                 // consecutive threads write consecutive floats
+    for (int e = threadIdx.x; e < PP_BLOCK * 3 && e < lim; e += PP_BLOCK) dcolor[base * 3 + e] = l_col[e];
+}
+
+hipError_t dvs_launch_dcolor_from_rows(hipStream_t st, int64_t total, const int* radii, const uint32_t* flags, const float* rows, float* dcolor) {
+    if (total <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((total + PP_BLOCK - 1) / PP_BLOCK);
+    hipLaunchKernelGGL(k_dcolor_from_rows, dim3(grid), dim3(PP_BLOCK), 0, st, total, radii, flags, (const float4*)rows, dcolor);
+    return hipGetLastError();
+}
+
 hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, float* dst, int to_tiled) {
     if (n <= 0) return hipSuccess;
     const int grid = (((n + 63) / 64) * 64 + PP_BLOCK - 1) / PP_BLOCK;      // cover the pad lanes of the last tile

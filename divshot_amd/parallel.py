@@ -77,8 +77,10 @@ class FactorisedExchange:
     On MI355X's point-to-point xGMI links the exchange is bandwidth-bound, so this is ~2.5x less exposed time.
     """
 
-    def __init__(self, n, device, world, views_per_rank=1):
-        self.n, self.world, self.views_per_rank = n, world, views_per_rank
+    def __init__(self, n, device, world, views_per_rank=1, rank_major=False):
+        """rank_major: dcolor_all[r * views_per_rank + v] = view v of rank r — the layout ONE all-gather of all local views produces
+        (gather_all); default view-major, one all-gather per view (gather_view)."""
+        self.n, self.world, self.views_per_rank, self.rank_major = n, world, views_per_rank, rank_major
         # dcolor_local[v] = colour gradient of this rank's v-th view; after the all-gathers dcolor_all[v*world + r] = view v of
         # rank r (view-major, so the slots of one view are one contiguous all-gather output; `slots()` lists the order)
         self.dcolor_local = torch.zeros((views_per_rank, n, 3), dtype=torch.float32, device=device)
@@ -96,7 +98,35 @@ class FactorisedExchange:
 
     def slots(self):
         """[(rank, local_view)] for every slot of dcolor_all, in order — index the per-view camera table with this."""
+        if self.rank_major:
+            return [(r, v) for r in range(self.world) for v in range(self.views_per_rank)]
         return [(r, v) for v in range(self.views_per_rank) for r in range(self.world)]
+
+    def gather_all(self, ready=None, group=None):
+        """rank_major layout: ONE all-gather of all local views' colour gradients, started on the side stream as soon as `ready`
+        (a CUDA event recorded behind dvs_raster_backward_dcolor) has passed — it runs under the preprocess backward (A9), so only
+        the geometry all-reduce stays exposed at the end of the step."""
+        import torch.distributed as dist
+        assert self.rank_major
+        def run():
+            if self.world == 1 and not (_force() and dist.is_initialized()):
+                self.dcolor_all.copy_(self.dcolor_local)
+                return
+            try:
+                dist.all_gather_into_tensor(self.dcolor_all.view(-1), self.dcolor_local.view(-1), group=group)
+            except (RuntimeError, NotImplementedError):
+                per = self.views_per_rank
+                dist.all_gather([self.dcolor_all[r * per:(r + 1) * per] for r in range(self.world)], self.dcolor_local, group=group)
+        if self._comm is None:
+            run()
+        else:
+            if ready is not None:
+                self._comm.wait_event(ready)
+            else:
+                self._comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                run()
+        self._gathered = [True] * self.views_per_rank
 
     def _gather(self, v, group):
         import torch.distributed as dist
@@ -133,9 +163,13 @@ class FactorisedExchange:
     def communicate(self, gbuf, group=None):
         """all-gather of the views not gathered yet + all-reduce(geometry slice). Complete on the current stream on return."""
         import torch.distributed as dist
-        for v in range(self.views_per_rank):
-            if not self._gathered[v]:
-                self.gather_view(v, None, group)
+        if self.rank_major:
+            if not all(self._gathered):
+                self.gather_all(None, group)
+        else:
+            for v in range(self.views_per_rank):
+                if not self._gathered[v]:
+                    self.gather_view(v, None, group)
         self._gathered = [False] * self.views_per_rank
         self._n_combined = 0
         if self.world > 1 or (_force() and dist.is_initialized()):

@@ -253,6 +253,14 @@ class Rasterizer:
             check(lib.dvs_raster_backward_composite(self.ctx, _stream_ptr(), cam_arg, C.byref(self._opts), dL_drgb.data_ptr()),
                   "dvs_raster_backward_composite")
 
+    def backward_dcolor(self, dcolor):
+        """Between backward_composite and backward_project: the per-view colour gradients [V,n,3] (or [n,3]) straight from the A8
+        rows (dvs_raster_backward_dcolor) — what backward_project(factorised_sh=True) writes to grads["dcolor"], bit for bit."""
+        assert dcolor.is_cuda and dcolor.dtype == torch.float32 and dcolor.is_contiguous()
+        with torch.cuda.device(self.tdev):
+            check(lib.dvs_raster_backward_dcolor(self.ctx, _stream_ptr(), dcolor.data_ptr()), "dvs_raster_backward_dcolor")
+        return dcolor
+
     def backward_project(self, grads=None, accumulate=False, want_mean2d=False, factorised_sh=False):
         """A9 alone (dvs_raster_backward_project) after backward_composite; same arguments and result as backward()."""
         grads, opts, g = self._grad_args(grads, accumulate, want_mean2d, factorised_sh)

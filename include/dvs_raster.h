@@ -184,6 +184,11 @@ int dvs_raster_backward_composite(dvs_ctx* ctx, void* stream, const dvs_camera* 
 int dvs_raster_backward_project(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                                 const dvs_opts* opts, const dvs_splat_grads* out);
 
+/* Between dvs_raster_backward_composite and dvs_raster_backward_project: dcolor [n_views,n,3] (DEVICE, 16-byte aligned) receives
+ * the per-view colour gradients — the values dvs_raster_backward_project later writes to out->dcolor, bit for bit — so that a
+ * data-parallel trainer can start their all-gather while A9 runs. Does not consume the pending rows. */
+int dvs_raster_backward_dcolor(dvs_ctx* ctx, void* stream, float* dcolor);
+
 /* Rebuild SH gradient rows from per-view colour gradients: for every view v and splat i with dir = normalize(pos_i - campos_v):
  *   g_sh0[i] (+)= SH_C0 * dcolor[v,i],   g_shN[i,k] (+)= basis_k(dir) * dcolor[v,i].
  * This is exactly what dvs_raster_backward writes into sh0/shN for one view, summed over views; it lets data-parallel ranks

@@ -48,6 +48,33 @@ def test_pipelined_views_accumulate_like_sequential(gpu_device):
     assert g4["pos"] > 1.2 * g1["pos"]            # four different views accumulated, not one
 
 
+def test_bench_step_over_rccl_one_rank(gpu_device):
+    """bench.py's N>1 step — colour gradients taken from the A8 rows, their all-gather on the side stream under A9, geometry
+    all-reduce, SH rows rebuilt — executed over backend "nccl" (RCCL) with a 1-rank communicator, both exchanges: the gradient norms
+    must equal the plain single-process step."""
+    import socket
+    def run(force, exchange):
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if force:
+            env["DVS_FORCE_COLLECTIVES"] = "1"
+        else:
+            env.pop("DVS_FORCE_COLLECTIVES", None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "C2", "--no-cpu-baseline",
+               "--profile-iters", "0", "--global-views", "2", "--exchange", exchange]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    plain = run(False, "factorised")
+    assert plain["comm_microbench"] is None and not plain["config"]["early_gather"]
+    for exchange in ("factorised", "allreduce"):
+        forced = run(True, exchange)
+        assert forced["comm_microbench"] is not None                      # the collectives ran (RCCL, world 1)
+        assert forced["config"]["early_gather"] == (exchange == "factorised")
+        for k, v in plain["grad_l2_after_exchange"].items():
+            assert abs(forced["grad_l2_after_exchange"][k] - v) <= 1e-4 * v, (exchange, k, v, forced["grad_l2_after_exchange"][k])
+
+
 def test_rccl_one_rank_communicator(gpu_device):
     """Backend "nccl" (= RCCL on ROCm) for real, on the one GPU this box has: a 1-rank communicator runs every collective the
     multi-GPU step uses — all_reduce of the flat gradient buffer, all_gather_into_tensor on the exchange's side stream behind a

@@ -154,8 +154,9 @@ def test_pipeline_parity(rast, oracle_mod, name):
               "fragile_pixel_fraction": float(frag_any.mean()), "tainted_splat_fraction": float(tainted.mean()), "runs": {}}
 
     # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
-    # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-2 relative L2
-    # of the fp32 oracle (one flipped 1/255-alpha contribution moves a gradient by ~1e-3 of its magnitude).
+    # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-3 relative L2
+    # of the fp32 oracle (one flipped 1/255-alpha contribution moves a gradient by ~1e-3 of its magnitude; measured over all
+    # configurations, modes and kernels: at most 2.1e-4, profiles/r02b_parity_report.jsonl).
     def check_group(tag, rec, got, want64, want32):
         got = np.asarray(got, np.float64); want64 = np.asarray(want64, np.float64); want32 = np.asarray(want32, np.float64)
         scale = np.abs(want64).max()
@@ -176,7 +177,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
             worst = float((np.abs(g - w) / (1e-4 * np.abs(w) + 1e-5 * max(np.abs(want32).max(), 1e-300))).max())
             out["tainted_rel_l2_vs_fp32_oracle"] = float(l2); out["tainted_worst_err_over_tol"] = worst
             rec[tag] = out
-            assert l2 < 1e-2, f"{tag} (tainted set): relative L2 error {l2}"
+            assert l2 < 1e-3, f"{tag} (tainted set): relative L2 error {l2}"
 
     culled = saved["radii"] == 0
     oracle_grads = {}
@@ -706,8 +707,11 @@ def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     g2 = {k: g[k].clone() for k in ("pos", "scale", "rot", "opacity")}
     g2["dcolor"] = torch.empty((V, n, 3), device=batch.tdev)
     batch.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=tiled)
-    batch.backward_views(dL_all, grads=g2, accumulate=True, factorised_sh=True)
+    batch.backward_composite(dL_all)
+    early = batch.backward_dcolor(torch.full((V, n, 3), 7.0, device=batch.tdev))     # dvs_raster_backward_dcolor: before A9, from the A8 rows
+    batch.backward_project(grads=g2, accumulate=True, factorised_sh=True)
     torch.cuda.synchronize()
+    assert torch.equal(early, g2["dcolor"]), "dvs_raster_backward_dcolor differs from the colour gradients A9 emits"
     for v in range(V):
         m, worst = rel_close(g2["dcolor"][v].cpu().numpy(), ref_dcol[v].cpu().numpy(), 1e-4, 2e-6)
         assert m.all(), (v, worst)
