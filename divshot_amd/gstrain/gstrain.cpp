@@ -95,6 +95,8 @@ struct GaussianTrainerScene::Impl {
     // per million splats. DVS_EXCHANGE=allreduce: one all-reduce of all 59-float rows.
     bool factorised = true; size_t geom_floats = 0;
     float* d_dcolor_local = nullptr; float* d_dcolor_all = nullptr;          // [cap,3] / [world,n,3]
+    float* d_dcolor_scratch = nullptr;                                       // A9's own copy of the colour gradient (the all-gather reads the early one)
+    hipStream_t comm_stream = nullptr; hipEvent_t ev_dcolor = nullptr, ev_bwd = nullptr, ev_comm = nullptr;   // collectives run beside A9
     std::vector<uint8_t*> d_targets_u8; float* d_target_f32 = nullptr;       // packLevel & PackF32ToU8
     std::vector<float*> d_masks;                                             // useMask
     std::vector<float> init_host[6];                                         // initial splats (resetGaussian, getPoints3D)
@@ -127,7 +129,9 @@ struct GaussianTrainerScene::Impl {
         d_targets_u8.clear();
         for (float* t : d_masks) (void)hipFree(t);
         d_masks.clear();
-        for (float** p : {&d_grad_flat, &d_mean2d, &d_target_f32, &d_dcolor_local, &d_dcolor_all}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (float** p : {&d_grad_flat, &d_mean2d, &d_target_f32, &d_dcolor_local, &d_dcolor_all, &d_dcolor_scratch}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (hipEvent_t* e : {&ev_dcolor, &ev_bwd, &ev_comm}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        if (comm_stream) { (void)hipStreamDestroy(comm_stream); comm_stream = nullptr; }
         if (comm) { dvs_comm_destroy(comm); comm = nullptr; }
         for (void** p : {(void**)&d_grad_accum, (void**)&d_denom, (void**)&d_max_radii, (void**)&d_action, (void**)&d_offsets,
                          (void**)&d_dscratch, (void**)&d_newcount, &d_mcmc}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -560,14 +564,26 @@ void GaussianTrainerScene::trainStep() {
     g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = absgrad ? m.d_absgrad : nullptr;
     g.mean2d = (!absgrad && !mcmc && refining) ? m.d_mean2d : nullptr;      // ADC without abs-grad: the norm of dL/dmean2D is the statistic
     const bool fact = m.comm && m.factorised;
-    if (fact) {             // the SH rows are not written by the backward: only the view's colour gradient, rebuilt after the exchange
+    if (fact) {
+        // The SH rows are not written by the backward: only the view's colour gradient, which leaves right after the composite
+        // backward (dvs_raster_backward_dcolor) so that its all-gather runs on the communication stream while A9 computes.
         if (!m.d_dcolor_local) {
             HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_local, (size_t)m.cap * 3 * sizeof(float) + 16));
+            HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_scratch, (size_t)m.cap * 3 * sizeof(float) + 16));
             HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_all, (size_t)m.world * m.cap * 3 * sizeof(float) + 16));
+            HIP_OR_THROW(hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&m.ev_dcolor, &m.ev_bwd, &m.ev_comm}) HIP_OR_THROW(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
-        g.sh0 = nullptr; g.shN = nullptr; g.dcolor = m.d_dcolor_local;
+        g.sh0 = nullptr; g.shN = nullptr; g.dcolor = m.d_dcolor_scratch;
+        DVS_OR_THROW(dvs_raster_backward_composite(m.ctx, m.stream, &m.cams[ci], &opts, m.d_dL));
+        DVS_OR_THROW(dvs_raster_backward_dcolor(m.ctx, m.stream, m.d_dcolor_local));
+        HIP_OR_THROW(hipEventRecord(m.ev_dcolor, m.stream));
+        HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_dcolor, 0));
+        DVS_OR_THROW(dvs_comm_all_gather_f32(m.comm, m.comm_stream, m.d_dcolor_local, m.d_dcolor_all, (size_t)m.n * 3));
+        DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, &m.cams[ci], &opts, &g));
+    } else {
+        DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
     }
-    DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
     if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule)
         DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
     if (refining && !mcmc) {    // densification statistics of this view; summed over the ranks in densify()
@@ -580,9 +596,12 @@ void GaussianTrainerScene::trainStep() {
     }
     // data parallel, over RCCL / xGMI: all-gather of the views' colour gradients + all-reduce of the geometry groups, then every
     // replica rebuilds the summed SH rows from all views (factorised) — or ONE sum-all-reduce of all six groups (they share a buffer)
-    if (fact) {
-        DVS_OR_THROW(dvs_comm_all_gather_f32(m.comm, m.stream, m.d_dcolor_local, m.d_dcolor_all, (size_t)m.n * 3));
-        DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.stream, m.d_grad_flat, m.geom_floats));
+    if (fact) {             // (both collectives on the communication stream, in the same order on every rank)
+        HIP_OR_THROW(hipEventRecord(m.ev_bwd, m.stream));
+        HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_bwd, 0));
+        DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad_flat, m.geom_floats));
+        HIP_OR_THROW(hipEventRecord(m.ev_comm, m.comm_stream));
+        HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_comm, 0));
         std::vector<float> campos((size_t)m.world * 3);
         for (int r = 0; r < m.world; ++r) for (int k = 0; k < 3; ++k) campos[(size_t)r * 3 + k] = m.cams[(size_t)ci_all[(size_t)r]].campos[k];
         DVS_OR_THROW(dvs_sh_grad_combine(m.ctx, m.stream, m.n, m.d_param[P_POS], deg, m.world, campos.data(), m.d_dcolor_all,
