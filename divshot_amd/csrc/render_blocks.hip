@@ -325,6 +325,7 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
         __syncthreads();
         const int len = (int)L.cnt[block];
         const int nmax = __builtin_amdgcn_readfirstlane(wave_max4(len));
+        const int lastb = (int)min(last, (uint32_t)(base + BK_RB)) - base;         // entries of this batch below the pixel's last contributor
         int idx = len - 1;
         int jn = idx >= 0 ? (int)lp[idx] : 0;
 #pragma unroll 1
@@ -332,7 +333,6 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             const bool act = idx >= 0;
             const int j = jn;
             jn = idx >= 1 ? (int)lp[idx - 1] : 0;
-            const uint32_t k = (uint32_t)(base + j);
             const float4 xy = L.xyc[j];
             const float4 zo4 = L.zoir[j];
             const float2 zo2 = make_float2(zo4.x, zo4.y);
@@ -341,7 +341,7 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             const float G = __builtin_amdgcn_exp2f(p2);
             const float oa = zo2.y * G;
             const float alpha = fminf(DVS_ALPHA_MAX, oa);
-            const bool contrib = act && (k < last) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
+            const bool contrib = act && (j < lastb) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
             if (__builtin_amdgcn_ballot_w64(contrib) == 0) continue;
             const float4 cg = L.cog[j];
             const float3 c = make_float3(zo4.w, cg.w, zo4.z);
@@ -353,7 +353,8 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
             float dL_dalpha = cd * T - D * inv_1ma;
             D = D + cd * w;
             // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE: it passes as if alpha = opacity * G
-            dL_dalpha = (contrib && (lineage || !(oa > DVS_ALPHA_MAX))) ? dL_dalpha : 0.f;
+            const bool capped = !lineage && (oa > DVS_ALPHA_MAX);
+            dL_dalpha = (contrib && !capped) ? dL_dalpha : 0.f;
             const float v5 = G * dL_dalpha;
             const float sw = zo2.y * v5;
             const float su = sw * dx, st = sw * dy;
