@@ -617,6 +617,10 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
     float g_op = 0.f;
     float2 ag = make_float2(0.f, 0.f), dm = make_float2(0.f, 0.f);
     float* l_col = lds;
+    // which views see the splat: all radii are requested up front, so that a view costs ONE dependent memory round trip (its rows
+    // and flags) instead of two (radius, then rows) — the kernel is latency-bound at two waves per SIMD
+    uint32_t vis = 0;
+    for (int view = 0; view < n_views; ++view) vis |= (valid && radii[(int64_t)view * n + il] > 0) ? (1u << view) : 0u;
 
     for (int view = 0; view < n_views; ++view) {
         const DvsCam cam = dvs_load_cam(view);
@@ -625,9 +629,8 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
         // loop — they are cheap to recompute and would otherwise stay live across it
         float s0_ = in_s0, s1_ = in_s1, s2_ = in_s2, q0_ = in_q.x, q1_ = in_q.y, q2_ = in_q.z, q3_ = in_q.w, op_ = in_op;
         if (NOHOIST) asm volatile("" : "+v"(s0_), "+v"(s1_), "+v"(s2_), "+v"(q0_), "+v"(q1_), "+v"(q2_), "+v"(q3_), "+v"(op_));
-        const int radius = valid ? radii[o] : 0;
         float gcol[3] = {0.f, 0.f, 0.f};
-        if (radius > 0) {
+        if ((vis >> view) & 1u) {
             const float4 r0 = grad_rows[3 * o], r1 = grad_rows[3 * o + 1], r2 = grad_rows[3 * o + 2];
             if (rezero) {
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
