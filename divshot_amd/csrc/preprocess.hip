@@ -616,7 +616,6 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
     float gp[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
     float g_op = 0.f;
     float2 ag = make_float2(0.f, 0.f), dm = make_float2(0.f, 0.f);
-    float* l_col = lds;
     // which views see the splat: all radii are requested up front, so that a view costs ONE dependent memory round trip (its rows
     // and flags) instead of two (radius, then rows) — the kernel is latency-bound at two waves per SIMD
     uint32_t vis = 0;
@@ -649,19 +648,26 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
             float gc[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch]; gcol[ch] = gc[ch]; }
-            // the coefficients come from the tiled array again for every view: after the first view they are L2 hits, and keeping
-            // 48 of them in registers across the loop would halve the occupancy
+            // The coefficients come from the tiled array again for every view (after the first view they are L2 hits; keeping 48 of
+            // them in registers across the loop would cost more registers than there are). They are requested in three groups of
+            // four 16-B chunks, unconditionally: basis derivatives above `deg` are zero, so unused bands drop out by themselves — a
+            // test per chunk made every chunk its own dependent L2 round trip (12 per view in a latency-bound kernel).
+            if (deg > 0) {
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                if (c * 4 < (ncoef - 1) * 3) {
-                    const float4 q = p4[shn_tiled_f4(i, c)];
-                    const float qv[4] = {q.x, q.y, q.z, q.w};
+                for (int g4 = 0; g4 < 3; ++g4) {
+                    float4 q4[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = c * 4 + u;                     // compile-time: coefficient k = e/3 + 1, channel e%3
-                        if (e < 45 && e / 3 + 1 < ncoef) {
-                            const int k = e / 3 + 1, ch = e % 3;
-                            gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                    for (int c = 0; c < 4; ++c) q4[c] = p4[shn_tiled_f4(i, g4 * 4 + c)];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float qv[4] = {q4[c].x, q4[c].y, q4[c].z, q4[c].w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = (g4 * 4 + c) * 4 + u;              // compile-time: coefficient k = e/3 + 1, channel e%3
+                            if (e < 45) {
+                                const int k = e / 3 + 1, ch = e % 3;
+                                gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                            }
                         }
                     }
                 }
@@ -681,12 +687,13 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
             ag.x += r2.y; ag.y += r2.z;
             dm.x += dmv.x; dm.y += dmv.y;
         }
-        // per-view colour gradient, always overwritten (zero for culled splats and clamped channels)
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) l_col[threadIdx.x * 3 + k] = gcol[k];
-        __syncthreads();
-        stage_rows_out<3, false>(out_dcolor + (size_t)view * n * 3, l_col, base, n);
+        // per-view colour gradient, always overwritten (zero for culled splats and clamped channels). Stored straight from the lane
+        // (three 4-B stores at stride 12; the L2 merges them): staging it through LDS for full-line stores cost two workgroup barriers
+        // per view, which this latency-bound kernel feels more than the partial-line writes
+        if (valid) {
+            float* dc = out_dcolor + ((size_t)view * n + (size_t)i) * 3;
+            dc[0] = gcol[0]; dc[1] = gcol[1]; dc[2] = gcol[2];
+        }
     }
 
     if (valid) {
