@@ -156,7 +156,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
     # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
     # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-3 relative L2
     # of the fp32 oracle (one flipped 1/255-alpha contribution moves a gradient by ~1e-3 of its magnitude; measured over all
-    # configurations, modes and kernels: at most 2.1e-4, profiles/r02c_parity_report.jsonl).
+    # configurations, modes and kernels: at most 2.1e-4, profiles/r02d_parity_report.jsonl).
     def check_group(tag, rec, got, want64, want32):
         got = np.asarray(got, np.float64); want64 = np.asarray(want64, np.float64); want32 = np.asarray(want32, np.float64)
         scale = np.abs(want64).max()
