@@ -408,15 +408,16 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, con
     c->rows_pending = true;
     return DVS_OK;
 }
-// A9: rows -> parameter gradients (re-zeroes the rows it reads). A multi-view batch in the tiled layout goes through ONE pass that
+// A9: rows -> parameter gradients (re-zeroes the rows it reads). The tiled layout — one view or a batch — goes through ONE pass that
 // reads the parameters once and writes the geometry gradients once (+ the per-view colour gradients), the SH rows are then built from
-// those; otherwise (one view, or the reference's row layout) the per-view kernel runs once per view, accumulating.
+// those (also for a single view: that pass plus the row rebuild is faster than the fused per-view kernel, 0.09 vs 0.15 ms at C3);
+// the reference's row layout goes through the per-view kernel, once per view, accumulating.
 static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dvs_camera* cams, const dvs_opts* opts,
                        const dvs_splat_grads* out, StageTimer* tm) {
     const dvs_fwd_state& s = c->st;
     const int V = c->n_views, n = p->n;
     size_t e2 = tm ? tm->mark() : 0;
-    if (V > 1 && opts->shn_layout == DVS_SHN_TILED) {
+    if (opts->shn_layout == DVS_SHN_TILED) {
         DvsCams dcams;
         float campos[DVS_MAX_VIEWS * 3];
         for (int v = 0; v < V; ++v) { dcams.c[v] = to_dev_cam(cams[v]); for (int k = 0; k < 3; ++k) campos[3 * v + k] = cams[v].campos[k]; }
