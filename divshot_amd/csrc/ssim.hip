@@ -106,8 +106,9 @@ k_ssim_fwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
         dm_ds12[o] = 2.f * Cn * iAB;
     }
     const float s = block_sum256(local, tmp);
-    // one atomic per workgroup, spread over DVS_SSIM_SLOTS addresses (30k same-address atomics serialise for ~0.3 ms)
-    if (threadIdx.x == 0 && ssim_sum) atomicAdd(ssim_sum + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (DVS_SSIM_SLOTS - 1)), s);
+    // one atomic per workgroup, spread over DVS_SSIM_SLOTS addresses by the linear workgroup id (same-address atomics serialise at
+    // ~0.3 us each on the memory side: with 64 slots they were 0.1 ms of this kernel)
+    if (threadIdx.x == 0 && ssim_sum) atomicAdd(ssim_sum + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (DVS_SSIM_SLOTS - 1)), s);
 }
 
 // L1 = true: the kernel also adds the L1 term of the photometric loss, dL = l1_scale * sign(x - y) + scale * dSSIM/dx, and accumulates
@@ -156,7 +157,7 @@ k_ssim_bwd(const float* __restrict__ img, const float* __restrict__ tgt, int W, 
     if (L1) {
         __shared__ float tmp[4];
         const float t = block_sum256(l1_local, tmp);
-        if (threadIdx.x == 0 && l1_sum) atomicAdd(l1_sum + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (DVS_SSIM_SLOTS - 1)), t);
+        if (threadIdx.x == 0 && l1_sum) atomicAdd(l1_sum + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (DVS_SSIM_SLOTS - 1)), t);
     }
 }
 

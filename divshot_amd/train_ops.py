@@ -22,7 +22,7 @@ class Ssim:
     def __init__(self, width, height, device):
         self.W, self.H = width, height
         self.maps = [torch.empty((3, height, width), dtype=torch.float32, device=device) for _ in range(3)]
-        self.sum = torch.zeros(64, dtype=torch.float32, device=device)        # DVS_SSIM_SLOTS partial sums
+        self.sum = torch.zeros(4096, dtype=torch.float32, device=device)      # DVS_SSIM_SLOTS partial sums
 
     def forward(self, img, target):
         """-> mean SSIM as a 1-element tensor (asynchronous)."""
@@ -35,7 +35,7 @@ class Ssim:
         """After forward(): dL of (1-w) mean|x-y| + w (1 - mean SSIM) in one pass (dvs_loss_l1_ssim_backward).
         -> (dL [3,H,W], l1 term as a 1-element tensor = (1-w) mean|x-y|)."""
         dL = torch.empty_like(img)
-        l1 = torch.zeros(64, dtype=torch.float32, device=img.device)
+        l1 = torch.zeros(4096, dtype=torch.float32, device=img.device)            # DVS_SSIM_SLOTS
         check(lib.dvs_loss_l1_ssim_backward(_st(), img.data_ptr(), target.data_ptr(), self.W, self.H, self.maps[0].data_ptr(),
                                             self.maps[1].data_ptr(), self.maps[2].data_ptr(), float(ssim_weight), dL.data_ptr(), l1.data_ptr()),
               "dvs_loss_l1_ssim_backward")
