@@ -96,19 +96,37 @@ k_sort_hist(const uint32_t* __restrict__ keys, uint64_t n_host, const uint64_t* 
     }
 }
 
-// one workgroup per digit: exclusive scan of its row of per-block counts, row total -> totals[d]
-__global__ void __launch_bounds__(SORT_BLOCK)
+// one workgroup (16 waves) per digit: exclusive scan of its row of per-block counts, row total -> totals[d]. Wave w owns a contiguous
+// segment of the row and reads it in rows of 64 consecutive counts (coalesced); with 1024 threads a wave has 6 such rows at 24 M keys.
+#define ROWSCAN_THREADS 1024
+__global__ void __launch_bounds__(ROWSCAN_THREADS)
 k_sort_rowscan(uint32_t* __restrict__ hist, uint32_t num_blocks, uint32_t* __restrict__ totals) {
-    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    __shared__ uint32_t wsum[ROWSCAN_THREADS / 64];
     uint32_t* row = hist + (uint64_t)blockIdx.x * num_blocks;
-    // one round: thread t owns a contiguous chunk of the row (2-3 entries at 1M-3M keys)
-    const uint32_t per = (num_blocks + SORT_BLOCK - 1) / SORT_BLOCK;
-    const uint32_t lo = threadIdx.x * per, hi = min(num_blocks, lo + per);
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t rows_per_wave = (num_blocks + ROWSCAN_THREADS - 1) / ROWSCAN_THREADS;
+    const uint32_t seg = wave * rows_per_wave * 64u;
     uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += row[i];
-    uint32_t tot;
-    uint32_t run = block_excl_scan(s, tmp, &tot);
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = row[i]; row[i] = run; run += v; }
+    for (uint32_t r = 0; r < rows_per_wave; ++r) {
+        const uint32_t i = seg + r * 64u + lane;
+        s += i < num_blocks ? row[i] : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    uint32_t carry = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < ROWSCAN_THREADS / 64; ++w) { const uint32_t t = wsum[w]; if ((uint32_t)w < wave) carry += t; tot += t; }
+    for (uint32_t r = 0; r < rows_per_wave; ++r) {
+        const uint32_t i = seg + r * 64u + lane;
+        const uint32_t v = i < num_blocks ? row[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+        if (i < num_blocks) row[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
     if (threadIdx.x == 0) totals[blockIdx.x] = tot;
 }
 
@@ -216,7 +234,7 @@ hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const u
     const uint32_t dmask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
     if (items == 8) hipLaunchKernelGGL(k_sort_hist<8>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, n, n_dev, shift, dmask, hist, nb);
     else hipLaunchKernelGGL(k_sort_hist<16>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, n, n_dev, shift, dmask, hist, nb);
-    hipLaunchKernelGGL(k_sort_rowscan, dim3(RADIX), dim3(SORT_BLOCK), 0, st, hist, nb, totals);
+    hipLaunchKernelGGL(k_sort_rowscan, dim3(RADIX), dim3(ROWSCAN_THREADS), 0, st, hist, nb, totals);
     if (items == 8)
         hipLaunchKernelGGL(k_sort_scatter<8>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, n_dev, shift,
                            dmask, hist, totals, nb);
