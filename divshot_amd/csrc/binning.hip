@@ -10,8 +10,8 @@
 // Reference anchors: key idea gsplat_viewz_cs.hlsl:250-253, sortable float gaussian_common.hlsl:115-120,
 // the viewer's own 8-bit-digit LSD sort renderer/gpu_sort.cpp:16-25,54-91 (32-bit keys, Vulkan; not reused).
 //
-// Wave64 idioms: digits are ranked with 8 ballots + mbcnt (a 64-wide multisplit), per-wave digit
-// counters live in LDS, no LDS atomics on the hot path.
+// Wave64 idioms: in the scatter, digits are ranked with 8 ballots + mbcnt (a stable 64-wide multisplit) and per-wave digit
+// counters in LDS; the histogram pass, which needs no ranks, counts with native integer LDS atomics (ds_add_u32).
 #include "dvs_device.h"
 #include "dvs_kernels.h"
 
