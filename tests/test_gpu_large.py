@@ -71,3 +71,43 @@ def test_full_size_properties(gpu_device, name, n, W, H, soff):
         assert rel < 1e-5, (k, rel)                      # atomics reorder fp32 sums: not bit-exact, but linear to 1e-5
         assert not bool(ga[k][culled].any()), k
     r.close()
+
+
+def test_c3_batch_of_views_equals_single_views(gpu_device):
+    """BASELINE config C4's unit of work at full size: a multi-view pass over three C3 cameras (asynchronous forward) gives, per
+    view, the image, the saved per-pixel state and the instance count of the single-view pass bit for bit, and the summed gradients
+    to fp32-atomics roundoff — with the default kernels (per-block A8, view-loop A9) on both sides."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H, V = 1_000_000, 1920, 1080, 3
+    spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=8)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, i) for i in (0, 3, 6)]
+    tg = [torch.from_numpy(dv.synth_target(spec, i)).cuda() for i in (0, 3, 6)]
+    single = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    batch = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+    batch.set_async(True)
+    Pd = params_to_device(P, single.tdev)
+    Pd["shN"] = single.shn_relayout(Pd["shN"], n, to_tiled=True)
+    ref, imgs1, T1, nc1 = None, [], 0, []
+    for v in range(V):
+        img = single.forward(Pd, cams[v], sh_degree=3, absgrad=True, shn_tiled=True)
+        imgs1.append(img.clone()); T1 += single.num_rendered
+        nc1.append(torch.from_numpy(single.saved()["n_contrib"].astype(np.int64)))
+        dL = ((img - tg[v]) / (W * H)).contiguous()
+        ref = single.backward(dL, grads=ref, accumulate=ref is not None)
+        if v == 0:
+            ref = {k: t.clone() for k, t in ref.items()}
+    imgs = batch.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True)
+    assert batch.get_num_rendered() == T1
+    for v in range(V):
+        assert torch.equal(imgs[v], imgs1[v]), f"image of view {v}"
+        assert np.array_equal(batch.view_saved(v)["n_contrib"].astype(np.int64), nc1[v].numpy()), f"n_contrib of view {v}"
+    dL_all = torch.stack([(imgs[v] - tg[v]) / (W * H) for v in range(V)]).contiguous()
+    g = batch.backward_views(dL_all)
+    torch.cuda.synchronize()
+    for k in ("pos", "sh0", "shN", "opacity", "scale", "rot"):
+        a, b = g[k].double(), ref[k].double()
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2e-6, (k, rel)
+    single.close(); batch.close()

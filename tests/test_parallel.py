@@ -59,6 +59,23 @@ def _worker_fact(rank, world, port, n, out):
         assert fx.slots() == [(r, v) for v in range(V) for r in range(world)]
         for s_, (r, v) in enumerate(fx.slots()):             # view-major slots
             assert torch.equal(fx.dcolor_all[s_], val(r, v)), (s_, r, v)
+    # rank-major layout: ONE all-gather of all local views (gather_all — what bench.py starts behind dvs_raster_backward_dcolor)
+    fr = FactorisedExchange(n, torch.device("cpu"), world, views_per_rank=V, rank_major=True)
+    for step in range(2):
+        gb.flat.zero_()
+        gb.flat_geom += (rank + 1) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+        fr.dcolor_all.fill_(float("nan"))
+        for v in range(V):
+            fr.dcolor_local[v].copy_(val(rank, v))
+        if step == 0:
+            fr.gather_all()                                  # early; communicate() must not gather again
+            fr.dcolor_local.fill_(float("nan"))
+        fr.communicate(gb)                                   # step 1: communicate() does the gather itself
+        want = sum(range(1, world + 1)) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+        assert torch.allclose(gb.flat_geom, want, rtol=1e-6)
+        assert fr.slots() == [(r, v) for r in range(world) for v in range(V)]
+        for s_, (r, v) in enumerate(fr.slots()):
+            assert torch.equal(fr.dcolor_all[s_], val(r, v)), (s_, r, v)
     out.put((rank, float(gb.flat_geom.sum())))
     dist.destroy_process_group()
 
