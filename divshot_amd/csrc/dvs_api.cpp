@@ -188,7 +188,8 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
     if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e, __FILE__, __LINE__); return nullptr; }
     dvs_ctx* c = new dvs_ctx();
     c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h; c->max_views = max_views;
-    if (const char* v = getenv("DVS_BWD_VARIANT")) c->bwd_variant = v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_BLOCKS;
+    if (const char* v = getenv("DVS_BWD_VARIANT"))
+        c->bwd_variant = v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : v[0] == '3' ? DVS_BWD_TR : v[0] == '4' ? DVS_BWD_TR64 : DVS_BWD_BLOCKS;
     if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
     if (hipMalloc((void**)&c->total_dev, 16) != hipSuccess || hipHostMalloc((void**)&c->total_host, 16, hipHostMallocDefault) != hipSuccess ||
         hipMemset(c->total_dev, 0, 16) != hipSuccess) {
@@ -396,7 +397,11 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, con
     float bgs[DVS_MAX_VIEWS * 3];
     for (int v = 0; v < V; ++v) for (int k = 0; k < 3; ++k) bgs[3 * v + k] = cams[v].bg[k];
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
-    if (c->bwd_variant == DVS_BWD_BLOCKS)
+    if (c->bwd_variant == DVS_BWD_TR || c->bwd_variant == DVS_BWD_TR64)
+        HIPCHECK(dvs_launch_render_bwd_tr(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d, bgs, s.final_T,
+                                          s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
+                                          c->bwd_variant == DVS_BWD_TR64 ? 64 : 32));
+    else if (c->bwd_variant == DVS_BWD_BLOCKS)
         HIPCHECK(dvs_launch_render_bwd_blocks(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d,
                                               bgs, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
     else
@@ -593,7 +598,7 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
 }
 
 int dvs_set_backward_variant(dvs_ctx* c, int variant) {
-    if (!c || (variant != DVS_BWD_BLOCKS && variant != DVS_BWD_MM && variant != DVS_BWD_REDUCE)) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
+    if (!c || variant < DVS_BWD_BLOCKS || variant > DVS_BWD_TR64) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
     c->bwd_variant = variant;
     return DVS_OK;
 }

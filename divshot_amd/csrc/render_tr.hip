@@ -1,0 +1,360 @@
+// render_tr.hip — A8 (alpha-composite backward), variant "tr": per-pixel recurrence and per-splat accumulation are split, and the
+// (pixel, splat) pairs change hands through a small LDS transposition buffer instead of a cross-lane reduction per visit.
+//
+// The round-2 kernel (render_blocks.hip) spends 41 of its 81 vector instructions per list step on forming the 11 per-pixel
+// partials of a (splat, 4x4 block) pair, folding them over the block's 16 lanes (9 v_permlane*_swap + 15 v_add + 6 ds_swizzle) and
+// merging the group totals into the per-wave table. Every one of those sums is linear in just TWO per-pixel scalars of the pair,
+//     v5 = G dL/dalpha   and   w = alpha T,
+// against factors that depend on the pixel alone (its coordinates, its upstream gradient). So:
+//   phase 1 (lane = pixel; the sequential part): the same per-4x4-block lists and back-to-front recurrence as before, but a step
+//            ends when (v5, w) are known: they go into slot s of the wave's transposition buffer TB[slot][v5 | w][64 lanes].
+//   phase 2 (every 4 steps; lane = (block g, slot s, pixel row r)): each lane reads the four pixels of ITS row of ITS (block, slot)
+//            pair as two ds_read_b128, and accumulates serially in registers: row moments A = sum v5, B = sum x v5, C = sum x^2 v5
+//            (x = 0..3: two FMAs each), moved to the splat's mean algebraically (S_x = Dx A - B, S_xx = Dx S_x - (Dx B - C), ...:
+//            exact algebra, fp32 roundoff of the same size as the direct sums), the colour sums sum w dL/dC (the lane keeps its four
+//            pixels' upstream gradients in registers), and the abs-grad sums with the per-pixel linear forms stepped by one
+//            subtraction per pixel. The four rows of a pair sit in the four 16-lane rows of the wave, so the only cross-lane work
+//            left is the two packing swaps (v_permlane32_swap / v_permlane16_swap: 8 swaps + 9 adds per FOUR steps instead of 9 + 15
+//            + 6 swizzles per step), after which each of the four lanes owns three of the pair's twelve totals and adds them to the
+//            per-wave table (plain read-add-write, one block group at a time, as in render_blocks.hip).
+// Per list step: 32 + 80 / 4 = 52 vector instructions instead of 81 (ISA count, abs-grad on). The cursor is one saturating subtract:
+// the sixteen lists are stored interleaved behind a row of sentinels that point at an all-zero dummy entry (opacity 0 -> alpha 0 ->
+// "does not contribute"), so an exhausted group needs no predicate.
+//
+// Same inputs and the same 48-B row contract (moments about the mean, see dvs_get_bwd_intermediates) as the other A8 kernels; the
+// opacity factor of the moment / abs-grad sums is applied once per (tile, splat) when the tables are published.
+// Reference anchors as in render.hip (alpha rule gsplat_ps.hlsl:60-65, 16x16 groups gaussian_common.hlsl:162-163, abs-grad main.cpp:44).
+#include <cstdlib>
+#include "dvs_device.h"
+#include "dvs_kernels.h"
+#include "render_common.h"
+
+#define TR_SLOTS 4
+#define TR_SS 136          // floats per slot of the transposition buffer: two planes of 64 + 8 pad — with the phase-2 lane map below the
+                           // ds_read_b128 of a wave hit 16 distinct 16-B bank groups per service group (brute-forced over the gfx950 lane groups)
+#ifndef TR_MINW
+#define TR_MINW 6          // waves per SIMD the kernel is compiled for (register cap 96): with 80 (6 waves) the round's temporaries spill
+#endif
+#ifndef TR_WAVES32
+#define TR_WAVES32 6       // waves per SIMD the BK = 32 instantiation is compiled for (register cap)
+#endif
+
+template <int BK>
+struct __attribute__((aligned(16))) TrLds {
+    float4 ea[BK + 1];            // mean x, mean y, cs.x, cs.y          (cs = exponent constants, see render.hip); [BK] = all-zero dummy
+    float4 eb[BK + 1];            // cs.z, opacity, colour r, colour g
+    float4 ec[BK + 1];            // colour b, conic a, b, c
+    uint2 idop[2][BK];            // splat id (row of the gradient table), opacity bits — by batch parity: the publish of batch b reads them
+                                  // while batch b - 1 is being staged
+    uint8_t list[(BK + 1) * 16];  // element k (1-based, list order) of block b at k * 16 + b; row 0 = sentinels (BK)
+    uint32_t cnt[16];             // list lengths
+    uint32_t blast[16];           // per block: deepest contributor of any of its pixels
+};
+
+// The gather of a batch: splat ids, then the 64-B records. (Measured: requesting them a batch ahead and carrying them across the list
+// loop in registers costs more registers than the kernel has at six waves per SIMD — the spills then serialise the loads.)
+struct TrRec { uint32_t id; float4 r0, r1; float bl; };
+template <int BK>
+__device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt) {
+    const int e = threadIdx.x % BK;
+    return e < cnt ? sorted_splat[first + e] : 0u;
+}
+template <int BK>
+__device__ __forceinline__ TrRec tr_load_rec(const float4* __restrict__ splat2d, uint32_t id, int cnt) {
+    TrRec R;
+    R.id = id; R.r0 = make_float4(0.f, 0.f, 0.f, 0.f); R.r1 = R.r0; R.bl = 0.f;
+    if ((int)(threadIdx.x % BK) < cnt) {
+        R.r0 = splat2d[4 * (size_t)id]; R.r1 = splat2d[4 * (size_t)id + 1]; R.bl = splat2d[4 * (size_t)id + 2].x;
+    }
+    return R;
+}
+
+// Stage the `cnt` entries of a batch (list positions base ..) and build the sixteen block lists. Thread t handles entry t % BK and the
+// GPT = 16 BK / 256 consecutive blocks starting at GPT * (t / BK) (one block row for BK = 64, half a row for BK = 32). All threads
+// holding one block sit in one wave (BK = 64) or one half wave (BK = 32), so ranks and lengths come straight from that wave's ballots.
+template <int BK>
+__device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, int base, int parity, float tile_x0, float tile_y0) {
+    constexpr int GPT = 16 * BK / RB;
+    static_assert(GPT == 4 || GPT == 2, "BK must be 64 or 32");
+    const int t = threadIdx.x, e = t % BK, sub = t / BK, lane = t & 63;
+    const int b0 = GPT * sub, row = b0 >> 2, col0 = b0 & 3;
+    uint32_t hits = 0;
+    if (e < cnt) {
+        const float4 r0 = R.r0, r1 = R.r1;
+        const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
+        if (sub == 0) {
+            L.ea[e] = make_float4(r0.x, r0.y, -0.72134752044448170f * a, -1.4426950408889634f * b);
+            L.eb[e] = make_float4(-0.72134752044448170f * c, op, r1.z, r1.w);
+            L.ec[e] = make_float4(R.bl, a, b, c);
+            L.idop[parity][e] = make_uint2(R.id, __float_as_uint(op));
+        }
+        // exact ellipse-vs-block test from non-negative terms (derivation: render_blocks.hip stage_blocks / render.hip stage_batch)
+        const float bound = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op) * 1.0001f + 1e-3f;
+        const float det = fmaxf(0.f, __builtin_fmaf(-2.4e-7f, a * c, a * c - b * b));
+        const float rc = __builtin_amdgcn_rcpf(c), ra = __builtin_amdgcn_rcpf(a);
+        const float det_c = det * rc, det_a = det * ra, nb_c = -b * rc, nb_a = -b * ra;
+        const float ox = tile_x0 - r0.x + 4.f * (float)col0, oy = tile_y0 - r0.y + 4.f * (float)row;
+        const float y0 = oy, y1 = oy + 3.f;
+        const bool hin = y0 <= 0.f && y1 >= 0.f;
+        const float ye = y0 > 0.f ? y0 : y1;
+        const float hx = nb_a * ye, hbase = hin ? __builtin_inff() : ye * ye * det_a;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const float x0 = ox + 4.f * (float)i, x1 = x0 + 3.f;
+            const bool vin = x0 <= 0.f && x1 >= 0.f;
+            const float xe = x0 > 0.f ? x0 : x1;
+            const float vy = nb_c * xe, vbase = vin ? __builtin_inff() : xe * xe * det_c;
+            const float ty_ = fminf(fmaxf(vy, y0), y1) - vy, tx_ = fminf(fmaxf(hx, x0), x1) - hx;
+            const float ev = __builtin_fmaf(c * ty_, ty_, vbase), eh = __builtin_fmaf(a * tx_, tx_, hbase);
+            const float qm = (vin && hin) ? 0.f : fminf(ev, eh);
+            bool h = !(qm > bound);                                       // NaN-safe: a failed comparison keeps the entry
+            h = h && ((uint32_t)(base + e) < L.blast[b0 + i]);            // entries at or beyond the block's deepest contributor never contribute there
+            hits |= h ? (1u << i) : 0u;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const uint64_t m = __ballot((hits >> i) & 1u);
+        uint32_t rk, len;
+        if (BK == 64) {
+            rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            len = (uint32_t)__popcll(m);
+        } else {                               // two 32-entry halves per wave, each a different block pair
+            const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+            const bool up = lane >= 32;
+            rk = up ? __builtin_amdgcn_mbcnt_hi(hi, 0u) : __builtin_amdgcn_mbcnt_lo(lo, 0u);
+            len = (uint32_t)__popc(up ? hi : lo);
+        }
+        if ((hits >> i) & 1u) L.list[(rk + 1u) * 16u + (uint32_t)(b0 + i)] = (uint8_t)e;
+        if (e == 0) L.cnt[b0 + i] = len;
+    }
+}
+
+template <bool ABSGRAD, bool LINEAGE, int BK>
+__global__ void __launch_bounds__(RB, TR_MINW)
+k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
+                int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
+                const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
+                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg /*experiment knobs (timing only)*/) {
+    __shared__ TrLds<BK> L;
+    __shared__ float s_tab[4][(BK + 1) * 12];               // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
+    __shared__ __attribute__((aligned(16))) float s_tb[4][TR_SLOTS * TR_SS];  // per wave: slot, plane (v5 | w), phase-1 lane
+    (void)bg_arg;
+    const int tile_g = tile_of_block(blockIdx.x, num_tiles);
+    if (tile_g >= num_tiles) return;
+    const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
+    const float3 bgv = dvs_load_bg(view);
+    final_T += (size_t)view * W * H; n_contrib += (size_t)view * W * H; dL_dout += (size_t)view * 3 * W * H;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t P = (size_t)W * H;
+    // phase-1 role: group g1 = lane >> 4 (one 16-lane row = one 4x4 block of the wave's 8x8 quadrant), pixel i = lane & 15
+    const int g1 = lane >> 4, pi = lane & 15;
+    const int bx1 = 2 * (wave & 1) + (g1 & 1), by1 = 2 * (wave >> 1) + (g1 >> 1), blk1 = by1 * 4 + bx1;
+    const int px = tx * DVS_TILE + 4 * bx1 + (pi & 3), py = ty * DVS_TILE + 4 * by1 + (pi >> 2);
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile_g];
+    // phase-2 role: pixel row r = lane >> 4, slot s = (lane >> 2) & 3, block g2 = lane & 3
+    const int r2 = lane >> 4, s2 = (lane >> 2) & 3, g2 = lane & 3;
+    const int bx2 = 2 * (wave & 1) + (g2 & 1), by2 = 2 * (wave >> 1) + (g2 >> 1);
+    const int X0 = tx * DVS_TILE + 4 * bx2, Y0 = ty * DVS_TILE + 4 * by2 + r2;
+    const float X0f = (float)X0, Y0f = (float)Y0;
+    float d2[4][3];                                           // upstream gradient of the four pixels (X0 + x, Y0) this lane sums in phase 2
+#pragma unroll                                                // (measured: fetching them per round instead — three global loads, or twelve
+    for (int x = 0; x < 4; ++x) {                             //  ds_bpermute from the phase-1 lanes — doubles the cost of a round)
+        const bool in2 = X0 + x < W && Y0 < H;
+        const size_t q = (size_t)Y0 * W + X0 + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d2[x][c] = in2 ? dL_dout[c * P + q] : 0.f;
+    }
+    const int perm_r = (r2 == 1) ? 2 : (r2 == 2) ? 1 : r2;    // value index inside each packed register after the two swaps
+    const int xaddr = (lane ^ 32) << 2;
+    const int jaddr = (16 * g2) << 2;                         // any lane of phase-1 row g2 holds that group's slot -> entry map
+    const uint32_t jshift = 8u * (uint32_t)(TR_SLOTS - 1 - s2);
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f;
+    if (inside) { dLp0 = dL_dout[pix]; dLp1 = dL_dout[P + pix]; dLp2 = dL_dout[2 * P + pix]; }
+    const float bg_dot = (bgv.x * dLp0 + bgv.y * dLp1) + bgv.z * dLp2;
+
+    // deepest contributor per block (= per 16-lane row) and of the tile
+    uint32_t bmax = last;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, d, 64));
+    if (pi == 0) L.blast[blk1] = bmax;
+    for (int e = threadIdx.x; e < 4 * (BK + 1) * 12; e += RB) (&s_tab[0][0])[e] = 0.f;
+    if (threadIdx.x < 16) L.list[threadIdx.x] = (uint8_t)BK;
+    if (threadIdx.x == 0) { L.ea[BK] = make_float4(0.f, 0.f, 0.f, 0.f); L.eb[BK] = make_float4(0.f, 0.f, 0.f, 0.f); L.ec[BK] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __syncthreads();
+    uint32_t todo = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) todo = max(todo, L.blast[g]);
+    if (todo == 0) return;
+
+    float T = T_final;
+    float D = T_final * bg_dot;          // see k_render_bwd: one scalar of "colour behind" state suffices
+    float* const tbw = &s_tb[wave][lane];                                 // phase 1 writes (v5, w) of slot s at tbw[TR_SS s], tbw[TR_SS s + 64]
+    const float* const tbr = &s_tb[wave][TR_SS * s2 + 16 * g2 + 4 * r2];  // phase 2 reads its row of four pixels: v5 at tbr[0..3], w at tbr[64..67]
+    float* const tabw = &s_tab[wave][perm_r];
+    const uint8_t* const lbase = &L.list[0];
+
+    // phase 2: the wave's TR_SLOTS x 4 (slot, block) pairs, four lanes (pixel rows) per pair
+    auto flush = [&](uint32_t jpack) {
+        if (dbg & 4) return;
+        const uint32_t jp = (uint32_t)__builtin_amdgcn_ds_bpermute(jaddr, (int)jpack);
+        const int j = (int)((jp >> jshift) & 0xffu);
+        const float4 V = *reinterpret_cast<const float4*>(tbr);
+        const float4 Wv = *reinterpret_cast<const float4*>(tbr + 64);
+        const float2 mean = *reinterpret_cast<const float2*>(&L.ea[j]);
+        const float4 cq = L.ec[j];                                        // colour b | conic a, b, c
+        const float Dx = mean.x - X0f, Dy = mean.y - Y0f;                 // d = mean - pixel for the row's first pixel; pixel x: Dx - x
+        const float A0 = (V.x + V.y) + (V.z + V.w);
+        const float B0 = __builtin_fmaf(3.f, V.w, __builtin_fmaf(2.f, V.z, V.y));
+        const float C0 = __builtin_fmaf(9.f, V.w, __builtin_fmaf(4.f, V.z, V.y));
+        float v[12];
+        v[0] = __builtin_fmaf(Dx, A0, -B0);                               // S_x  = sum v5 (Dx - x)
+        v[1] = Dy * A0;                                                   // S_y
+        v[2] = __builtin_fmaf(Dx, v[0], -__builtin_fmaf(Dx, B0, -C0));    // S_xx = sum v5 (Dx - x)^2 = Dx S_x - (Dx B - C)
+        v[3] = Dy * v[0];                                                 // S_xy
+        v[4] = Dy * v[1];                                                 // S_yy
+        v[5] = A0;                                                        // S_o
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            v[6 + c] = __builtin_fmaf(Wv.w, d2[3][c], __builtin_fmaf(Wv.z, d2[2][c], __builtin_fmaf(Wv.y, d2[1][c], Wv.x * d2[0][c])));
+        if (ABSGRAD) {
+            // |dL/dmean2D| per pixel = |v5| |(a dx + b dy, b dx + c dy)| (times the opacity, applied at publish); linear in x
+            const float gx0 = __builtin_fmaf(cq.y, Dx, cq.z * Dy), gy0 = __builtin_fmaf(cq.z, Dx, cq.w * Dy);
+            const float gx1 = gx0 - cq.y, gx2 = gx1 - cq.y, gx3 = gx2 - cq.y;
+            const float gy1 = gy0 - cq.z, gy2 = gy1 - cq.z, gy3 = gy2 - cq.z;
+            v[9] = __builtin_fmaf(fabsf(V.w), fabsf(gx3), __builtin_fmaf(fabsf(V.z), fabsf(gx2), __builtin_fmaf(fabsf(V.y), fabsf(gx1), fabsf(V.x) * fabsf(gx0))));
+            v[10] = __builtin_fmaf(fabsf(V.w), fabsf(gy3), __builtin_fmaf(fabsf(V.z), fabsf(gy2), __builtin_fmaf(fabsf(V.y), fabsf(gy1), fabsf(V.x) * fabsf(gy0))));
+        } else { v[9] = 0.f; v[10] = 0.f; }
+        v[11] = 0.f;
+        // fold the four pixel rows (the four 16-lane rows of the wave) with the packing swaps: afterwards row r holds, in q[k], the
+        // total of value 4 k + perm(r) of its (block, slot) pair
+        const float h0 = swap32_add(v[0], v[1]), h1 = swap32_add(v[2], v[3]), h2 = swap32_add(v[4], v[5]);
+        const float h3 = swap32_add(v[6], v[7]);
+        float h4, h5;
+        if (ABSGRAD) {
+            h4 = swap32_add(v[8], v[9]);
+            h5 = v[10] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[10])));
+        } else {
+            h4 = v[8] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[8])));
+            h5 = 0.f;
+        }
+        const float q0 = swap16_add(h0, h1), q1 = swap16_add(h2, h3), q2 = swap16_add(h4, h5);
+        // one block group at a time: two groups may hold the same entry (measured: in nearly every round); LDS operations of one wave
+        // execute in order, so a later group sees an earlier group's write
+        float* const slot = tabw + j * 12;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g2 == g) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
+
+    const int nbatch = (int)((todo + BK - 1) / BK);
+    const float tile_x0 = (float)(tx * DVS_TILE), tile_y0 = (float)(ty * DVS_TILE);
+    for (int b = nbatch - 1; b >= 0; --b) {
+        const int base = b * BK;
+        const int cnt = min(BK, (int)todo - base);
+        // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
+        {
+            const TrRec R = tr_load_rec<BK>(splat2d, tr_load_id<BK>(sorted_splat, range.x + base, cnt), cnt);
+            tr_stage<BK>(L, R, cnt, base, b & 1, tile_x0, tile_y0);
+        }
+        __syncthreads();                                    // batch staged; the tables are zero again
+        const int len = (int)L.cnt[blk1];
+        int nmax = len;
+        nmax = max(nmax, __shfl_xor(nmax, 16, 64));
+        nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        const int lastb = (int)min(last, (uint32_t)(base + BK)) - base;          // entries of this batch below the pixel's last contributor
+        uint32_t p = (uint32_t)len * 16u + (uint32_t)blk1;                         // byte offset of the list's last element
+        uint32_t jn = lbase[p];
+        uint32_t jpack = 0;
+        int nslot = 0;
+#pragma unroll 1
+        for (int it = 0; it < ((dbg & 8) ? 0 : nmax); ++it) {
+            const int j = (int)jn;
+            p = __builtin_elementwise_sub_sat(p, 16u);                             // an exhausted list parks on the sentinel row
+            jn = lbase[p];
+            const float4 ea = L.ea[j];
+            const float4 eb = L.eb[j];
+            const float dx = ea.x - pxf, dy = ea.y - pyf;
+            const float p2 = __builtin_fmaf(eb.x * dy, dy, __builtin_fmaf(ea.w, dy, ea.z * dx) * dx);   // same expression as the forward
+            const float G = __builtin_amdgcn_exp2f(p2);
+            const float oa = eb.y * G;
+            const float alpha = fminf(DVS_ALPHA_MAX, oa);
+            const bool contrib = (j < lastb) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
+            if (__builtin_amdgcn_ballot_w64(contrib) == 0) continue;
+            const float2 rg = make_float2(eb.z, eb.w);
+            const float cb = L.ec[j].x;
+            const float al = contrib ? alpha : 0.f;
+            const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);
+            T = T * inv_1ma;
+            const float w = al * T;
+            const float cd = (rg.x * dLp0 + rg.y * dLp1) + cb * dLp2;
+            const float dL_dalpha = cd * T - D * inv_1ma;
+            D = D + cd * w;
+            // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE: it passes as if alpha = opacity * G
+            const bool gate = LINEAGE ? contrib : (contrib && !(oa > DVS_ALPHA_MAX));
+            const float v5 = gate ? G * dL_dalpha : 0.f;
+            tbw[TR_SS * nslot] = v5;
+            tbw[TR_SS * nslot + 64] = w;
+            jpack = (jpack << 8) | (uint32_t)j;
+            if (++nslot == TR_SLOTS) { flush(jpack); nslot = 0; }
+        }
+        if (nslot > 0) {                                    // pad the unfinished round with the dummy entry (zero pairs, sink row)
+            for (; nslot < TR_SLOTS; ++nslot) {
+                tbw[TR_SS * nslot] = 0.f; tbw[TR_SS * nslot + 64] = 0.f;
+                jpack = (jpack << 8) | (uint32_t)BK;
+            }
+            flush(jpack);
+        }
+        __syncthreads();                                    // tables complete; nobody reads the staged entries or lists any more
+        // the tile's total per touched (entry, value): ONE global atomic each — consecutive threads add consecutive floats of a row.
+        // The moment and abs-grad sums were taken over v5 = G dL/dalpha; the row contract wants them over opacity * v5.
+        for (int e = threadIdx.x; e < cnt * 12; e += RB) {
+            const float val = (s_tab[0][e] + s_tab[1][e]) + (s_tab[2][e] + s_tab[3][e]);
+            if (val != 0.f) {
+                const int ent = e / 12, comp = e - 12 * ent;
+                const uint2 io = L.idop[b & 1][ent];
+                const float sc = (comp == 5 || (comp >= 6 && comp <= 8)) ? 1.f : __uint_as_float(io.y);
+                if (comp < 11 && !(dbg & 1)) atomicAdd(&grow[(size_t)io.x * 12 + comp], val * sc);
+            }
+            s_tab[0][e] = 0.f; s_tab[1][e] = 0.f; s_tab[2][e] = 0.f; s_tab[3][e] = 0.f;
+        }
+    }
+}
+
+// ---- launcher -------------------------------------------------------------------------------------------
+hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+                                    const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T,
+                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode, int batch) {
+    const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
+    if (num_tiles <= 0) return hipSuccess;
+    const int grid = ((num_tiles + 7) >> 3) << 3;
+    const int lineage = grad_mode == 1 ? 1 : 0;
+    const char* e_dbg = getenv("DVS_TR_DEBUG");
+    const int dbg = e_dbg ? atoi(e_dbg) : 0;
+    const char* e_lds = getenv("DVS_BWD_EXTRA_LDS");
+    const size_t extra_lds = e_lds ? (size_t)atoi(e_lds) : 0;
+#define DVS_TR(A, LN, BKV)                                                                                                          \
+    hipLaunchKernelGGL((k_render_bwd_tr<A, LN, BKV>), dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, \
+                       num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, dbg)
+#define DVS_TR_B(BKV)                                                                                   \
+    do {                                                                                                \
+        if (absgrad) { if (lineage) DVS_TR(true, true, BKV); else DVS_TR(true, false, BKV); }           \
+        else { if (lineage) DVS_TR(false, true, BKV); else DVS_TR(false, false, BKV); }                 \
+    } while (0)
+    if (batch == 64) DVS_TR_B(64); else DVS_TR_B(32);
+#undef DVS_TR_B
+#undef DVS_TR
+    return hipGetLastError();
+}

@@ -86,7 +86,7 @@ def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
     return img_h, saved, keys, runs, (img_h - tgt) / tgt[0].size
 
 
-BWD_VARIANTS = ("reduce", "blocks", "mm")
+BWD_VARIANTS = ("reduce", "blocks", "mm", "tr", "tr64")
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 

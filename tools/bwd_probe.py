@@ -29,7 +29,7 @@ def main():
         label, _, rest = cfg.partition(":")
         kv = dict(x.split("=") for x in rest.split(",") if x)
         variant, absgrad, fvar = kv.pop("variant", "blocks"), int(kv.pop("absgrad", "1")), kv.pop("fwd", "blocks")
-        for k in ("DVS_BWD_EXTRA_LDS", "DVS_MM_DEBUG"):
+        for k in ("DVS_BWD_EXTRA_LDS", "DVS_MM_DEBUG", "DVS_TR_DEBUG"):
             os.environ.pop(k, None)
         os.environ.update(kv)
         r.set_backward_variant(variant)
