@@ -154,8 +154,8 @@ def main():
                     help="if > 0: this many views PER GPU per step instead of sharding --global-views (weak scaling, the round-1 shape)")
     ap.add_argument("--shn-tiled", type=int, default=1,
                     help="1: shN parameters/gradients in the DVS_SHN_TILED HBM layout (default); 0: the reference's [N,45] rows")
-    ap.add_argument("--bwd-variant", default="blocks", choices=["blocks", "reduce", "mm", "tr", "tr64"],
-                    help="A8 kernel (dvs_set_backward_variant): blocks = default (measured winner); reduce (round 1) / mm = the measured alternatives")
+    ap.add_argument("--bwd-variant", default="tr", choices=["tr", "blocks", "reduce", "mm"],
+                    help="A8 kernel (dvs_set_backward_variant): tr = default (round 3, measured winner); blocks (round 2) / reduce (round 1) / mm = the measured alternatives")
     ap.add_argument("--fwd-variant", default="quadrant", choices=["blocks", "quadrant"], help="A7 kernel (dvs_set_forward_variant)")
     ap.add_argument("--grad-mode", type=int, default=0, help="dvs_opts.grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (same cost)")
     ap.add_argument("--early-gather", type=int, default=1,
@@ -483,7 +483,7 @@ def main():
             achieved = ab[dom] * views_per_launch / (dur_ms * 1e-3) / 1e9
             kern = "k_" + dom
             if dom == "render_bwd":
-                kern = {"blocks": "k_render_bwd_blocks<", "reduce": "k_render_bwd<", "mm": "k_render_bwd_mm<", "tr": "k_render_bwd_tr<", "tr64": "k_render_bwd_tr<"}[args.bwd_variant]
+                kern = {"blocks": "k_render_bwd_blocks<", "reduce": "k_render_bwd<", "mm": "k_render_bwd_mm<", "tr": "k_render_bwd_tr<"}[args.bwd_variant]
             traffic, traffic_src, same_run = None, None, False
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob

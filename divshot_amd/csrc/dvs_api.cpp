@@ -86,7 +86,7 @@ struct dvs_ctx {
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
-    int bwd_variant = DVS_BWD_BLOCKS;    // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create): the measured winner
+    int bwd_variant = DVS_BWD_TR;        // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create): the measured winner
     int fwd_variant = DVS_FWD_QUADRANT;  // which A7 kernel (dvs_set_forward_variant; env DVS_FWD_VARIANT at create)
     // stage timing: `timing` = every stage, synchronising per call (profiling iterations); `probe` = hipEvent pairs around the
     // composite kernels only, never synchronising — they are read back once, so the kernels are timed under the concurrency of
@@ -189,7 +189,7 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
     dvs_ctx* c = new dvs_ctx();
     c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h; c->max_views = max_views;
     if (const char* v = getenv("DVS_BWD_VARIANT"))
-        c->bwd_variant = v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : v[0] == '3' ? DVS_BWD_TR : v[0] == '4' ? DVS_BWD_TR64 : DVS_BWD_BLOCKS;
+        c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_TR;
     if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
     if (hipMalloc((void**)&c->total_dev, 16) != hipSuccess || hipHostMalloc((void**)&c->total_host, 16, hipHostMallocDefault) != hipSuccess ||
         hipMemset(c->total_dev, 0, 16) != hipSuccess) {
@@ -397,10 +397,9 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, con
     float bgs[DVS_MAX_VIEWS * 3];
     for (int v = 0; v < V; ++v) for (int k = 0; k < 3; ++k) bgs[3 * v + k] = cams[v].bg[k];
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
-    if (c->bwd_variant == DVS_BWD_TR || c->bwd_variant == DVS_BWD_TR64)
+    if (c->bwd_variant == DVS_BWD_TR)
         HIPCHECK(dvs_launch_render_bwd_tr(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d, bgs, s.final_T,
-                                          s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
-                                          c->bwd_variant == DVS_BWD_TR64 ? 64 : 32));
+                                          s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
     else if (c->bwd_variant == DVS_BWD_BLOCKS)
         HIPCHECK(dvs_launch_render_bwd_blocks(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d,
                                               bgs, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
@@ -598,7 +597,7 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
 }
 
 int dvs_set_backward_variant(dvs_ctx* c, int variant) {
-    if (!c || variant < DVS_BWD_BLOCKS || variant > DVS_BWD_TR64) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
+    if (!c || variant < DVS_BWD_BLOCKS || variant > DVS_BWD_TR) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
     c->bwd_variant = variant;
     return DVS_OK;
 }

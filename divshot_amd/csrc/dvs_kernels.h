@@ -67,15 +67,14 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
 enum { DVS_BWD_BLOCKS = 0 /*per-4x4-block lists, four cursors per wave, 12-value group reduction per step (round 2)*/, DVS_BWD_REDUCE = 1 /*per-quadrant
        masks, wave-wide reduction tree per visit (round 1)*/, DVS_BWD_MM = 2 /*per-quadrant masks, sums contracted on the fp32 matrix pipe (experiment)*/,
        DVS_BWD_TR = 3 /*per-4x4-block lists; (v5, w) pairs transposed through LDS and accumulated serially per (block, slot, pixel row):
-       render_tr.hip; batches of 32 list entries*/, DVS_BWD_TR64 = 4 /*the same with batches of 64 entries*/ };
+       render_tr.hip (default since round 3)*/ };
 // A7 kernel variants (dvs_set_forward_variant): bit-identical results
 enum { DVS_FWD_BLOCKS = 0 /*per-4x4-block lists (experiment)*/, DVS_FWD_QUADRANT = 1 /*per-quadrant masks walked by the scalar unit (default)*/ };
 
 // render_tr.hip
 hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                     const uint32_t* sorted_splat, const float* splat2d, const float* bgs /*[n_views][3]*/, const float* final_T,
-                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode,
-                                    int batch /*list entries per batch: 32 or 64*/);
+                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode);
 
 // render_blocks.hip
 hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,

@@ -33,10 +33,7 @@
 #define TR_SS 136          // floats per slot of the transposition buffer: two planes of 64 + 8 pad — with the phase-2 lane map below the
                            // ds_read_b128 of a wave hit 16 distinct 16-B bank groups per service group (brute-forced over the gfx950 lane groups)
 #ifndef TR_MINW
-#define TR_MINW 6          // waves per SIMD the kernel is compiled for (register cap 96): with 80 (6 waves) the round's temporaries spill
-#endif
-#ifndef TR_WAVES32
-#define TR_WAVES32 6       // waves per SIMD the BK = 32 instantiation is compiled for (register cap)
+#define TR_MINW 6          // waves per SIMD the kernel is compiled for (register cap 80; the LDS footprint allows six workgroups per CU)
 #endif
 
 template <int BK>
@@ -51,8 +48,9 @@ struct __attribute__((aligned(16))) TrLds {
     uint32_t blast[16];           // per block: deepest contributor of any of its pixels
 };
 
-// The gather of a batch: splat ids, then the 64-B records. (Measured: requesting them a batch ahead and carrying them across the list
-// loop in registers costs more registers than the kernel has at six waves per SIMD — the spills then serialise the loads.)
+// The gather of a batch: splat ids (requested before the previous batch is published, so that round trip runs under the publish), then
+// the 64-B records. (Measured: requesting the records a batch ahead too and carrying them across the list loop costs more registers
+// than the kernel has at six waves per SIMD — the spills then serialise the loads.)
 struct TrRec { uint32_t id; float4 r0, r1; float bl; };
 template <int BK>
 __device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt) {
@@ -193,7 +191,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     uint32_t todo = 0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) todo = max(todo, L.blast[g]);
-    if (todo == 0) return;
+    if (todo == 0 || (dbg & 64)) return;
 
     float T = T_final;
     float D = T_final * bg_dot;          // see k_render_bwd: one scalar of "colour behind" state suffices
@@ -260,12 +258,13 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
 
     const int nbatch = (int)((todo + BK - 1) / BK);
     const float tile_x0 = (float)(tx * DVS_TILE), tile_y0 = (float)(ty * DVS_TILE);
+    uint32_t id_stage = tr_load_id<BK>(sorted_splat, range.x + (nbatch - 1) * BK, min(BK, (int)todo - (nbatch - 1) * BK));
     for (int b = nbatch - 1; b >= 0; --b) {
         const int base = b * BK;
         const int cnt = min(BK, (int)todo - base);
         // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
         {
-            const TrRec R = tr_load_rec<BK>(splat2d, tr_load_id<BK>(sorted_splat, range.x + base, cnt), cnt);
+            const TrRec R = tr_load_rec<BK>(splat2d, id_stage, cnt);
             tr_stage<BK>(L, R, cnt, base, b & 1, tile_x0, tile_y0);
         }
         __syncthreads();                                    // batch staged; the tables are zero again
@@ -318,9 +317,10 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
             flush(jpack);
         }
         __syncthreads();                                    // tables complete; nobody reads the staged entries or lists any more
+        if (b > 0) id_stage = tr_load_id<BK>(sorted_splat, range.x + (b - 1) * BK, BK);     // the next batch's ids arrive under the publish
         // the tile's total per touched (entry, value): ONE global atomic each — consecutive threads add consecutive floats of a row.
         // The moment and abs-grad sums were taken over v5 = G dL/dalpha; the row contract wants them over opacity * v5.
-        for (int e = threadIdx.x; e < cnt * 12; e += RB) {
+        for (int e = threadIdx.x; e < ((dbg & 128) ? 0 : cnt * 12); e += RB) {
             const float val = (s_tab[0][e] + s_tab[1][e]) + (s_tab[2][e] + s_tab[3][e]);
             if (val != 0.f) {
                 const int ent = e / 12, comp = e - 12 * ent;
@@ -336,7 +336,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
 // ---- launcher -------------------------------------------------------------------------------------------
 hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                     const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T,
-                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode, int batch) {
+                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode) {
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
@@ -353,7 +353,7 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
         if (absgrad) { if (lineage) DVS_TR(true, true, BKV); else DVS_TR(true, false, BKV); }           \
         else { if (lineage) DVS_TR(false, true, BKV); else DVS_TR(false, false, BKV); }                 \
     } while (0)
-    if (batch == 64) DVS_TR_B(64); else DVS_TR_B(32);
+    DVS_TR_B(64);
 #undef DVS_TR_B
 #undef DVS_TR
     return hipGetLastError();

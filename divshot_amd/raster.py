@@ -98,8 +98,8 @@ class Rasterizer:
         return self.num_rendered
 
     def set_backward_variant(self, variant):
-        """A8 kernel: 3 / "tr" (render_tr.hip), 4 / "tr64", 0 / "blocks" (round 2), 1 / "reduce" (round 1), 2 / "mm" — see dvs_raster.h."""
-        v = {"blocks": 0, "reduce": 1, "mm": 2, "tr": 3, "tr64": 4}.get(variant, variant)
+        """A8 kernel: 3 / "tr" (default, render_tr.hip), 0 / "blocks" (round 2), 1 / "reduce" (round 1), 2 / "mm" — see dvs_raster.h."""
+        v = {"blocks": 0, "reduce": 1, "mm": 2, "tr": 3}.get(variant, variant)
         check(lib.dvs_set_backward_variant(self.ctx, int(v)), "dvs_set_backward_variant")
 
     def set_forward_variant(self, variant):

@@ -232,9 +232,11 @@ int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
 
 /* The composite kernels exist in several variants with the same inputs and outputs, kept selectable so that the measured
  * comparison can be repeated (all of them pass the same parity tests). Backward (A8), results equal to fp32 roundoff:
- *   0 "blocks"  (default, the measured winner since round 2) per-4x4-pixel-block splat lists built while a batch is staged; the four
- *               16-lane groups of a wave walk four different lists; group totals go into a per-wave LDS table with plain
- *               read-add-write, one group at a time; the four tables are summed and published once per (tile, splat, value)
+ *   3 "tr"      (default since round 3) per-4x4-pixel-block splat lists; a list step ends when the pair's two per-pixel scalars
+ *               (G dL/dalpha, alpha T) are known: they cross an LDS transposition buffer, and every four steps each lane sums one
+ *               pixel row of one (block, step) pair serially in registers (moments about the row origin moved to the mean
+ *               algebraically) — no cross-lane reduction per step; per-wave LDS tables, one global atomic per (tile, splat, value)
+ *   0 "blocks"  (round 2) the same lists; a 12-value reduction over the block's 16 lanes per step, group totals into the per-wave table
  *   1 "reduce"  (round 1) per-8x8-quadrant cull masks, a 12-value wave-wide reduction tree and one atomic row update per (wave, splat) visit
  *   2 "mm"      per-quadrant masks, the per-splat sums contracted on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); bound by its
  *               LDS footprint (3 workgroups per CU) and by the matrix and vector pipes not overlapping; one view per launch only
