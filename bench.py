@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — train views/s (fwd+bwd raster) at 1M splats, 1920x1080, SH degree 3, on 1/2/4/8 MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 either launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL) or started plainly, in which
+case it launches its N ranks itself the same way.
 A step = one training iteration's pass of the hot path over one batch of views = BASELINE.json config C4: 8 synthetic cameras per
 iteration over the replicated 1M-splat scene, SHARDED over the GPUs (8/N views per GPU: rank r renders views r, r+N, ...), i.e.
 strong scaling: the work of a step is fixed as N grows. Per view: A2..A7, dL/drgb = (rgb - target)/P, A8, A9, gradient rows
@@ -169,6 +170,17 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU under
+    # torch.distributed.run on 127.0.0.1, a free port); rank 0's JSON line passes through. Under a launcher (WORLD_SIZE set) run as a rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch
     import divshot_amd as dv
@@ -179,10 +191,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     dist = None
     ndev = max(1, torch.cuda.device_count())
+    if world > ndev and os.environ.get("DVS_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs over RCCL, this node has {ndev} "
+                         "(DVS_DIST_BACKEND=gloo lets a functional test oversubscribe one GPU)")
     dev_index = local_rank % ndev          # (a functional test may oversubscribe one GPU with a gloo group; normally 1 rank = 1 GPU)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)

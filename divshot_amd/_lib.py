@@ -102,6 +102,7 @@ _PROTOS = {
     "dvs_device_malloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "dvs_device_free": (None, [C.c_void_p, C.c_void_p]),
     "dvs_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "dvs_comm_bootstrap": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]),
     "dvs_comm_destroy": (None, [C.c_void_p]),
     "dvs_comm_rank": (C.c_int, [C.c_void_p]),
     "dvs_comm_world": (C.c_int, [C.c_void_p]),

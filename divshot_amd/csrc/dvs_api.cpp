@@ -354,7 +354,8 @@ static int check_fwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cam
     if ((size_t)p->n > c->max_splats || cam->width > c->max_w || cam->height > c->max_h) {
         g_last_error = "dvs_raster_forward: exceeds the capacity given to dvs_create"; return DVS_ERR_CAPACITY;
     }
-    if ((uint64_t)p->n * (uint64_t)V >= (1ull << 32)) { g_last_error = "dvs_raster_forward: n * n_views must stay below 2^32"; return DVS_ERR_CAPACITY; }
+    // (the scan / duplication launchers and kernels index the (view, splat) elements with int)
+    if ((uint64_t)p->n * (uint64_t)V >= (1ull << 31)) { g_last_error = "dvs_raster_forward: n * n_views must stay below 2^31"; return DVS_ERR_CAPACITY; }
     return DVS_OK;
 }
 

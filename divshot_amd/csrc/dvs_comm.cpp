@@ -1,5 +1,5 @@
 // dvs_comm.cpp — include/dvs_comm.h: RCCL behind a plain-C surface (data-parallel exchange of the training step).
-// librccl is dlopen()ed on first use; the unique id travels from rank 0 to the other ranks over one TCP connection each.
+// librccl is dlopen()ed on first use; the unique id travels from rank 0 to the other ranks over TCP on a dedicated bootstrap port.
 #include <hip/hip_runtime.h>
 #include <arpa/inet.h>
 #include <dlfcn.h>
@@ -13,6 +13,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <vector>
+#include <sys/time.h>
 #include "../../include/dvs_comm.h"
 #include "../../include/dvs_raster.h"
 
@@ -65,19 +67,58 @@ bool recv_all(int fd, void* p, size_t n) {
     while (n) { ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) return false; c += k; n -= (size_t)k; }
     return true;
 }
-// rank 0 hands the 128-byte id to world-1 peers; a peer retries the connection for up to ~120 s (ranks start at different times)
-bool exchange_id(ncclUniqueId* id, int rank, int world, const char* addr, int port, std::string& err) {
+// Bootstrap of the RCCL unique id over TCP. Rank 0 listens on the bootstrap port; every other rank connects (retrying while rank 0 is
+// not up yet), introduces itself with {magic, job nonce, rank} and gets {magic, id} back. Rank 0 serves every rank AT MOST ONCE and
+// keeps accepting until all world-1 distinct ranks have been served: a stray or stale connection (wrong magic / nonce / rank, or one
+// that sends nothing) is dropped without using up a slot. Every socket operation has a timeout and the whole exchange a deadline
+// (DVS_COMM_TIMEOUT_S, default 180 s), after which it fails with an error instead of hanging.
+constexpr uint32_t kMagic = 0x44565343u;            // "DVSC"
+struct Hello { uint32_t magic; uint32_t rank; uint64_t nonce; };
+struct Reply { uint32_t magic; uint32_t pad; char id[128]; };
+
+void set_timeouts(int fd, int seconds) {
+    timeval tv{}; tv.tv_sec = seconds; tv.tv_usec = 0;
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+}
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool exchange_id(void* id128, int rank, int world, const char* addr, int port, uint64_t nonce, double timeout_s, std::string& err) {
     if (world == 1) return true;
+    const double deadline = now_s() + timeout_s;
     if (rank == 0) {
         int ls = ::socket(AF_INET, SOCK_STREAM, 0);
         if (ls < 0) { err = "socket() failed"; return false; }
         int one = 1; setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
         sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
-        if (::bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || ::listen(ls, world) != 0) { err = "bind/listen on MASTER_PORT failed"; ::close(ls); return false; }
-        for (int k = 1; k < world; ++k) {
+        // listen on the rendezvous address only when it is a literal IPv4 address of this host (127.0.0.1 in single-node runs)
+        in_addr lit{};
+        if (addr && inet_pton(AF_INET, addr, &lit) == 1) {
+            sa.sin_addr = lit;
+            if (::bind(ls, (sockaddr*)&sa, sizeof sa) != 0) sa.sin_addr.s_addr = htonl(INADDR_ANY);
+            else goto bound;
+        }
+        if (::bind(ls, (sockaddr*)&sa, sizeof sa) != 0) {
+            err = "cannot bind the bootstrap port " + std::to_string(port) + " (in use? set DVS_COMM_PORT)"; ::close(ls); return false;
+        }
+    bound:
+        if (::listen(ls, world + 8) != 0) { err = "listen() on the bootstrap port failed"; ::close(ls); return false; }
+        set_timeouts(ls, 1);                                   // accept() wakes up once a second to check the deadline
+        std::vector<bool> served((size_t)world, false);
+        int left = world - 1;
+        while (left > 0) {
+            if (now_s() > deadline) { err = "timed out waiting for " + std::to_string(left) + " rank(s) to fetch the RCCL id"; ::close(ls); return false; }
             int fd = ::accept(ls, nullptr, nullptr);
-            if (fd < 0 || !send_all(fd, id, sizeof *id)) { err = "sending the RCCL id failed"; if (fd >= 0) ::close(fd); ::close(ls); return false; }
-            ::close(fd);
+            if (fd < 0) continue;                              // timeout tick / transient error
+            set_timeouts(fd, 5);
+            Hello h{};
+            const bool ok = recv_all(fd, &h, sizeof h) && h.magic == kMagic && h.nonce == nonce && h.rank >= 1 && h.rank < (uint32_t)world &&
+                            !served[h.rank];
+            if (ok) {
+                Reply r{}; r.magic = kMagic; memcpy(r.id, id128, 128);
+                if (send_all(fd, &r, sizeof r)) { served[h.rank] = true; --left; }
+            }
+            ::close(fd);                                       // (anything else: not one of ours, or a duplicate — no slot used)
         }
         ::close(ls);
         return true;
@@ -87,15 +128,44 @@ bool exchange_id(ncclUniqueId* id, int rank, int world, const char* addr, int po
     char pbuf[16]; snprintf(pbuf, sizeof pbuf, "%d", port);
     if (getaddrinfo(addr, pbuf, &hints, &res) != 0 || !res) { err = std::string("cannot resolve ") + addr; return false; }
     bool ok = false;
-    for (int attempt = 0; attempt < 1200 && !ok; ++attempt) {
+    while (!ok && now_s() < deadline) {
         int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-        if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) ok = recv_all(fd, id, sizeof *id);
-        if (fd >= 0) ::close(fd);
+        if (fd >= 0) {
+            set_timeouts(fd, 5);
+            if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+                Hello h{}; h.magic = kMagic; h.rank = (uint32_t)rank; h.nonce = nonce;
+                Reply r{};
+                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic) { memcpy(id128, r.id, 128); ok = true; }
+            }
+            ::close(fd);
+        }
         if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
     freeaddrinfo(res);
-    if (!ok) err = "no RCCL id from rank 0 (is it running and MASTER_ADDR / MASTER_PORT the same on every rank?)";
+    if (!ok) err = "no RCCL id from rank 0 within the deadline (is it running, and MASTER_ADDR / MASTER_PORT / DVS_COMM_PORT the same on every rank?)";
     return ok;
+}
+
+// Where the bootstrap listens. The launcher's own rendezvous store (torch.distributed.run) already listens on MASTER_PORT, so the id
+// travels on a dedicated port: DVS_COMM_PORT if set, otherwise MASTER_PORT + 1789 (wrapped into the unprivileged range).
+int bootstrap_port(int master_port) {
+    if (const char* p = getenv("DVS_COMM_PORT")) { const int v = atoi(p); if (v > 0 && v < 65536) return v; }
+    int port = master_port + 1789;
+    if (port >= 65536) port = 1024 + (port - 65536) % (65536 - 1024);
+    return port;
+}
+// Ranks of one job agree on a nonce without talking: the launcher's run id when there is one, else the rendezvous address itself.
+uint64_t job_nonce(const char* addr, int master_port) {
+    std::string key = std::string(addr ? addr : "") + ":" + std::to_string(master_port);
+    for (const char* name : {"DVS_COMM_NONCE", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID"})
+        if (const char* v = getenv(name)) { key += "|"; key += v; }
+    uint64_t h = 1469598103934665603ull;                     // FNV-1a
+    for (unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+    return h;
+}
+double bootstrap_timeout() {
+    if (const char* p = getenv("DVS_COMM_TIMEOUT_S")) { const double v = atof(p); if (v > 0) return v; }
+    return 180.0;
 }
 }  // namespace
 
@@ -112,16 +182,32 @@ struct dvs_comm {
 
 extern "C" {
 
-dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_addr, int master_port) {
-    std::string err;
+// rank / world < 1 and a null address / non-positive port each fall back to the launcher's environment, independently of one another
+static void resolve_rendezvous(int& rank, int& world, const char*& master_addr, int& master_port) {
     if (world < 1) {
         const char* r = getenv("RANK"); const char* w = getenv("WORLD_SIZE");
         rank = r ? atoi(r) : 0; world = w ? atoi(w) : 1;
-        if (!master_addr) master_addr = getenv("MASTER_ADDR");
-        if (master_port <= 0) { const char* p = getenv("MASTER_PORT"); master_port = p ? atoi(p) : 29500; }
     }
+    if (!master_addr || !*master_addr) master_addr = getenv("MASTER_ADDR");
     if (!master_addr || !*master_addr) master_addr = "127.0.0.1";
+    if (master_port <= 0) { const char* p = getenv("MASTER_PORT"); master_port = p ? atoi(p) : 0; }
     if (master_port <= 0) master_port = 29500;
+}
+
+int dvs_comm_bootstrap(int rank, int world, const char* master_addr, int master_port, void* id128) {
+    std::string err;
+    resolve_rendezvous(rank, world, master_addr, master_port);
+    if (!id128 || rank < 0 || rank >= world) { dvs_set_last_error("dvs_comm_bootstrap: bad argument"); return DVS_ERR_INVALID; }
+    if (!exchange_id(id128, rank, world, master_addr, bootstrap_port(master_port), job_nonce(master_addr, master_port), bootstrap_timeout(), err)) {
+        dvs_set_last_error(("dvs_comm_bootstrap: " + err).c_str());
+        return DVS_ERR_STATE;
+    }
+    return DVS_OK;
+}
+
+dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_addr, int master_port) {
+    std::string err;
+    resolve_rendezvous(rank, world, master_addr, master_port);
     if (rank < 0 || rank >= world) { dvs_set_last_error("dvs_comm_create: rank outside [0, world)"); return nullptr; }
     if (!g_rccl.load(err)) { dvs_set_last_error(("dvs_comm_create: " + err).c_str()); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { dvs_set_last_error("dvs_comm_create: hipSetDevice failed"); return nullptr; }
@@ -131,7 +217,10 @@ dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_ad
         ncclResult_t r = g_rccl.GetUniqueId(&id);
         if (r != 0) { dvs_set_last_error((std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r)).c_str()); return nullptr; }
     }
-    if (!exchange_id(&id, rank, world, master_addr, master_port, err)) { dvs_set_last_error(("dvs_comm_create: " + err).c_str()); return nullptr; }
+    if (!exchange_id(&id, rank, world, master_addr, bootstrap_port(master_port), job_nonce(master_addr, master_port), bootstrap_timeout(), err)) {
+        dvs_set_last_error(("dvs_comm_create: " + err).c_str());
+        return nullptr;
+    }
     dvs_comm* c = new dvs_comm();
     c->device = device; c->rank = rank; c->world = world;
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);

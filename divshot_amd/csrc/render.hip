@@ -528,9 +528,8 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
     // experiment knobs (tools/bwd_probe.py): extra dynamic LDS to lower the occupancy, debug bits that drop parts of the mm kernel
-    const char* e_lds = getenv("DVS_BWD_EXTRA_LDS"); const char* e_dbg = getenv("DVS_MM_DEBUG");
-    const size_t extra_lds = e_lds ? (size_t)atoi(e_lds) : 0;
-    const int dbg = e_dbg ? atoi(e_dbg) : 0;
+    static const int dbg = [] { const char* e = getenv("DVS_MM_DEBUG"); return e ? atoi(e) : 0; }();
+    const size_t extra_lds = dvs_experiment_extra_lds();
     if (variant == DVS_BWD_REDUCE) {
 #define DVS_RB(KERNEL)                                                                                                             \
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles, \

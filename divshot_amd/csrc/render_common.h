@@ -1,8 +1,22 @@
 // render_common.h — device helpers shared by the composite kernels (render.hip, render_blocks.hip).
 #pragma once
+#include <cstdlib>
 #include "dvs_device.h"
 
 #define RB 256
+
+// Experiment knob of the occupancy measurements (tools/bwd_probe.py): DVS_BWD_EXTRA_LDS = bytes of dynamic LDS added to the composite
+// backward launches so that fewer workgroups fit a CU. Read ONCE per process and clamped to what a launch can carry.
+static inline size_t dvs_experiment_extra_lds() {
+    static const size_t v = [] {
+        const char* e = getenv("DVS_BWD_EXTRA_LDS");
+        long x = e ? atol(e) : 0;
+        if (x < 0) x = 0;
+        if (x > 64 * 1024) x = 64 * 1024;
+        return (size_t)x;
+    }();
+    return v;
+}
 
 // Per-view backgrounds of a multi-view batch: FIRST kernel parameter of the composite kernels, read through the kernarg segment
 // pointer (see DvsCams in dvs_device.h). One launch covers the tiles of all views: global tile t = view * tiles_per_view + tile.

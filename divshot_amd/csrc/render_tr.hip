@@ -341,10 +341,8 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
-    const char* e_dbg = getenv("DVS_TR_DEBUG");
-    const int dbg = e_dbg ? atoi(e_dbg) : 0;
-    const char* e_lds = getenv("DVS_BWD_EXTRA_LDS");
-    const size_t extra_lds = e_lds ? (size_t)atoi(e_lds) : 0;
+    static const int dbg = [] { const char* e = getenv("DVS_TR_DEBUG"); return e ? atoi(e) : 0; }();      // ablation knobs of tools/bwd_probe.py (timing only)
+    const size_t extra_lds = dvs_experiment_extra_lds();
 #define DVS_TR(A, LN, BKV)                                                                                                          \
     hipLaunchKernelGGL((k_render_bwd_tr<A, LN, BKV>), dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, \
                        num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, dbg)

@@ -44,6 +44,10 @@ class GradBuffer:
             offs[k] = off
             off += (counts[k] + 3) & ~3
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        # floats per group INCLUDING its alignment pad, in flat order: what an element-wise consumer of `flat` (ShardedAdam) must be
+        # built from — sum(group_sizes) == flat.numel(); a group's learning rate then also covers its (always zero) pad floats
+        self.group_sizes = [(((counts[k] + 3) & ~3)) for k in FLAT_ORDER]
+        self.group_offsets = [offs[k] for k in FLAT_ORDER]
         self.views = {}
         for k in FLAT_ORDER:
             v = self.flat[offs[k]:offs[k] + counts[k]]
@@ -265,6 +269,9 @@ class ShardedAdam:
     def step(self, grads_flat, lr_scale=1.0):
         """One optimizer step on every rank's replica: after it, params_flat holds the updated parameters everywhere."""
         import torch.distributed as dist
+        if grads_flat.numel() != self.p.numel():
+            raise ValueError(f"ShardedAdam.step: gradient buffer has {grads_flat.numel()} floats, the parameters {self.p.numel()} "
+                             "(build both from GradBuffer.group_sizes)")
         self.step_no += 1
         n = self.p.numel()
         self._reduce_scatter(grads_flat)

@@ -8,8 +8,10 @@
  * libgstrain.so uses it inside train_step() when WORLD_SIZE > 1 (divshot_amd/gstrain/gstrain.cpp).
  *
  * librccl is opened with dlopen() when the first communicator is created, so libdvsraster.so has no load-time dependency on it.
- * Bootstrap: rank 0 creates the RCCL unique id and serves it over TCP on master_addr:master_port (the rendezvous address every
- * launcher exports as MASTER_ADDR / MASTER_PORT); the other ranks connect and read it. Plain C, int status codes as dvs_raster.h.
+ * Bootstrap: rank 0 creates the RCCL unique id and serves it over TCP on the rendezvous address every launcher exports as MASTER_ADDR,
+ * on a DEDICATED port (the launcher's own store already listens on MASTER_PORT): DVS_COMM_PORT if set, else MASTER_PORT + 1789. A
+ * peer introduces itself with {magic, job nonce, rank}; rank 0 serves every rank at most once, ignores anything else, and every
+ * step has a timeout (DVS_COMM_TIMEOUT_S, default 180 s: an error, never a hang). Plain C, int status codes as dvs_raster.h.
  */
 #ifndef DVS_COMM_H
 #define DVS_COMM_H
@@ -23,10 +25,14 @@ extern "C" {
 
 typedef struct dvs_comm dvs_comm;
 
-/* Create the communicator of this process on HIP device `device`. world < 1: rank / world / master are read from the environment
- * (RANK, WORLD_SIZE, MASTER_ADDR default 127.0.0.1, MASTER_PORT default 29500). A 1-rank communicator is valid (every collective is
- * then the identity, executed by RCCL all the same). Returns NULL on failure (dvs_last_error). Blocks until all ranks have joined. */
+/* Create the communicator of this process on HIP device `device`. world < 1: rank / world are read from the environment (RANK,
+ * WORLD_SIZE); master_addr NULL / master_port <= 0: MASTER_ADDR (default 127.0.0.1) / MASTER_PORT (default 29500) — each falls back
+ * on its own. A 1-rank communicator is valid (every collective is then the identity, executed by RCCL all the same). Returns NULL on
+ * failure (dvs_last_error). Blocks until all ranks have joined or the bootstrap deadline passes. */
 dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_addr, int master_port);
+/* The bootstrap step alone (no RCCL, no GPU): rank 0 hands the 128 bytes at id128 to every other rank, which receive them into id128.
+ * Same argument / environment rules as dvs_comm_create. DVS_OK, or DVS_ERR_STATE on a timeout / bind failure (dvs_last_error). */
+int dvs_comm_bootstrap(int rank, int world, const char* master_addr, int master_port, void* id128);
 void      dvs_comm_destroy(dvs_comm* comm);
 int       dvs_comm_rank(const dvs_comm* comm);
 int       dvs_comm_world(const dvs_comm* comm);

@@ -1,0 +1,80 @@
+"""The TCP bootstrap of the RCCL unique id (include/dvs_comm.h, dvs_comm_bootstrap) on CPU: three ranks, the launcher's environment
+(MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE) honoured, the id on a dedicated port next to a socket that already listens on
+MASTER_PORT (as torch.distributed.run's store does), a stray connection and a duplicate rank ignored, and a deadline instead of a
+hang when a rank never shows up. No GPU and no RCCL involved: this is host code."""
+import ctypes as C
+import os
+import socket
+import struct
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+RANK_CODE = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.environ["DVS_ROOT"])
+import divshot_amd as dv
+rank = int(os.environ["RANK"])
+buf = (C.c_ubyte * 128)(*([(7 * i + 3) % 251 for i in range(128)] if rank == 0 else [0] * 128))
+rc = dv.lib.dvs_comm_bootstrap(-1, -1, None, 0, buf)          # everything from the environment
+print("RESULT", rc, bytes(buf).hex(), dv.lib.dvs_last_error().decode() if rc else "")
+"""
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _spawn(rank, world, port, extra=None):
+    env = dict(os.environ, DVS_ROOT=ROOT, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("DVS_COMM_PORT", None)
+    env.update(extra or {})
+    return subprocess.Popen([sys.executable, "-c", RANK_CODE], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+
+
+def _result(p, timeout=120):
+    out, err = p.communicate(timeout=timeout)
+    line = [l for l in out.splitlines() if l.startswith("RESULT ")]
+    assert line, out + err
+    f = line[-1].split(" ", 3)
+    return int(f[1]), f[2], (f[3] if len(f) > 3 else "")
+
+
+def test_three_ranks_next_to_a_busy_master_port_with_strays():
+    port = _free_port()
+    store = socket.socket(); store.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    store.bind(("127.0.0.1", port)); store.listen(4)          # the launcher's own store occupies MASTER_PORT
+    boot = port + 1789 if port + 1789 < 65536 else 1024 + (port + 1789 - 65536) % (65536 - 1024)
+    r0 = _spawn(0, 3, port)
+    # strays on the bootstrap port while rank 0 waits: garbage, a silent connection, and a well-formed hello of the wrong job
+    deadline = time.time() + 30
+    while True:
+        try:
+            s = socket.create_connection(("127.0.0.1", boot), timeout=1); break
+        except OSError:
+            assert time.time() < deadline, "rank 0 never listened on the bootstrap port"
+            time.sleep(0.1)
+    s.sendall(b"GET / HTTP/1.0\r\n\r\n"); s.close()
+    silent = socket.create_connection(("127.0.0.1", boot), timeout=1)
+    wrong = socket.create_connection(("127.0.0.1", boot), timeout=1)
+    wrong.sendall(struct.pack("<IIQ", 0x44565343, 1, 12345)); wrong.close()
+    r1 = _spawn(1, 3, port)
+    r2 = _spawn(2, 3, port)
+    res = [_result(p) for p in (r0, r1, r2)]
+    silent.close(); store.close()
+    want = bytes((7 * i + 3) % 251 for i in range(128)).hex()
+    for rc, got, msg in res:
+        assert rc == 0, msg
+        assert got == want
+
+
+def test_missing_rank_times_out_with_an_error():
+    port = _free_port()
+    t0 = time.time()
+    rc, _, msg = _result(_spawn(0, 2, port, {"DVS_COMM_TIMEOUT_S": "3"}), timeout=60)
+    assert rc != 0 and "timed out" in msg and time.time() - t0 < 30
+    rc, _, msg = _result(_spawn(1, 2, port, {"DVS_COMM_TIMEOUT_S": "2"}), timeout=60)      # nobody serves
+    assert rc != 0 and "no RCCL id" in msg

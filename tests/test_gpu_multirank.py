@@ -22,6 +22,24 @@ def _run(exchange, port, vps=1):
     return json.loads(line)
 
 
+def test_bench_self_launch_two_ranks(gpu_device):
+    """`python bench.py --gpus 2 --steps 3` exactly as the driver types it (no launcher around it): bench.py starts its two ranks itself
+    under torch.distributed.run; here they share the one GPU of the test box over gloo. Rank 0 prints the one JSON line of BASELINE
+    config C4 (8 views per iteration, 4 per rank, strong scaling)."""
+    env = dict(os.environ, DVS_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "strong"
+    assert rec["config"]["views_per_step"] == 8 and rec["config"]["views_per_gpu_per_step"] == 4
+    assert rec["value"] > 0 and rec["t_comm_exposed_ms_per_step"] is not None
+
+
 @pytest.mark.parametrize("vps", [1, 2])
 def test_factorised_exchange_equals_allreduce(gpu_device, vps):
     """vps = views per GPU per step: 1 = the north-star's "one view per GPU"; 2 exercises the two-context software pipeline,
@@ -120,7 +138,7 @@ err = {k: float((gb.views[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30
 flat_before = gb.flat.clone(); gb.all_reduce(); torch.cuda.synchronize()
 err["allreduce_identity"] = float((gb.flat - flat_before).abs().max())
 # ShardedAdam: reduce_scatter -> Adam on the shard -> all_gather, against a second instance that skips the collectives
-sizes = [n * PARAM_WIDTH[k] for k in FLAT_ORDER]; lrs = [1e-3] * len(sizes)
+sizes = gb.group_sizes; lrs = [1e-3] * len(sizes)          # (the padded group sizes: params and gradients share GradBuffer's layout)
 p1 = torch.randn(sum(sizes), device=dev); p2 = p1.clone()
 a1 = ShardedAdam(p1, sizes, lrs, 1, 0); a1.step(gb.flat)
 os.environ["DVS_FORCE_COLLECTIVES"] = "0"

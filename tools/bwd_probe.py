@@ -14,6 +14,21 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("configs", nargs="*")
     a = ap.parse_args()
+    cfgs = a.configs or ["tr:variant=tr,fwd=quadrant", "blocks:variant=blocks,fwd=quadrant", "reduce:variant=reduce,fwd=quadrant"]
+    if len(cfgs) > 1:          # the launchers read their experiment knobs once per process: one process per configuration
+        import subprocess
+        for cfg in cfgs:
+            env = dict(os.environ)
+            for k in ("DVS_BWD_EXTRA_LDS", "DVS_MM_DEBUG", "DVS_TR_DEBUG"):
+                env.pop(k, None)
+            for x in cfg.partition(":")[2].split(","):
+                if "=" in x and x.split("=")[0].isupper():
+                    env[x.split("=")[0]] = x.split("=")[1]
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--reps", str(a.reps), cfg], env=env,
+                               capture_output=True, text=True)
+            sys.stdout.write("".join(l + "\n" for l in p.stdout.splitlines() if l.startswith("{")) or p.stderr[-2000:])
+            sys.stdout.flush()
+        return
     import numpy as np, torch
     import divshot_amd as dv
     from divshot_amd.raster import Rasterizer, params_to_device
@@ -25,7 +40,7 @@ def main():
     cam = dv.synth_camera(spec, 0)
     tgt = torch.from_numpy(dv.synth_target(spec, 0)).to(dev)
     r = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
-    for cfg in a.configs or ["blocks:variant=blocks", "reduce:variant=reduce,fwd=quadrant", "mm:variant=mm"]:
+    for cfg in cfgs:
         label, _, rest = cfg.partition(":")
         kv = dict(x.split("=") for x in rest.split(",") if x)
         variant, absgrad, fvar = kv.pop("variant", "blocks"), int(kv.pop("absgrad", "1")), kv.pop("fwd", "blocks")
