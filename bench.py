@@ -425,7 +425,8 @@ def main():
         torch.cuda.synchronize()
         ms_view = ev0.elapsed_time(ev1) / n_strict
         strict = {"ms_per_view": ms_view, "views_per_s": 1e3 / ms_view, "views": n_strict,
-                  "note": "one view at a time on one stream (forward incl. its host sync on T, upstream gradient, backward); hipEvents"}
+                  "note": "one view at a time on one stream (forward" + ("" if args.async_forward else " incl. its host sync on T") + ", upstream gradient, backward); hipEvents",
+                  "async_forward": bool(args.async_forward)}
     clocks = read_clocks(dev_index) if rank == 0 else None
     # ---- the composite kernels timed inside the real step: a replica of the timed region with hipEvent pairs around k_render_fwd /
     # k_render_bwd on the streams they are launched on, never synchronised in between (dvs_enable_kernel_probe). Same concurrency as
@@ -498,13 +499,15 @@ def main():
             kern = "k_" + dom
             if dom == "render_bwd":
                 kern = {"blocks": "k_render_bwd_blocks<", "reduce": "k_render_bwd<", "mm": "k_render_bwd_mm<", "tr": "k_render_bwd_tr<"}[args.bwd_variant]
-            traffic, traffic_src, same_run = None, None, False
+            traffic, traffic_src, same_run, counter_bytes_step = None, None, False, None
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob
                 tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]      # the latest round's PMC passes
                 tj = json.load(open(tfile))
                 # the counters belong to the workload and batch shape they were collected on; any other run reports null
                 same_run = args.workload == tj.get("workload", "C3") and views_per_launch == tj.get("views_per_launch", 8)
+                if same_run and world == 1:
+                    counter_bytes_step = tj.get("counter_bytes_per_step")
                 for kname, rec_ in tj["kernels"].items():
                     if same_run and kname.startswith(kern):
                         traffic = rec_["hbm_bytes_per_launch_corrected"]
@@ -518,7 +521,7 @@ def main():
             try:
                 import glob, re
                 sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")))[-1]
-                dur_us = act = insts = None
+                dur_us = act = insts = gui = None
                 for line in open(sq):
                     if not line.lstrip().startswith(kern):
                         continue
@@ -527,11 +530,22 @@ def main():
                         act = float(f[-1])
                     elif "SQ_INSTS_VALU" in f:
                         insts = float(f[-1])
+                    elif "GRBM_GUI_ACTIVE" in f:
+                        gui = float(f[-1])
                     elif dur_us is None and len(f) > 6 and re.fullmatch(r"[0-9.]+", f[-10] or ""):
                         dur_us = float(f[-10])          # avg_us column of the kernel-trace table
                 if dur_us and act and same_run:
                     valu = {"source": "profiles/" + os.path.basename(sq), "insts_valu_per_launch": insts, "active_quads_per_launch": act,
-                            "avg_us_under_pmc": dur_us, "busy_fraction_at_2.4GHz": act * 4.0 / (1024 * dur_us * 1e-6 * 2.4e9)}
+                            "avg_us_under_pmc": dur_us}
+                    if gui:
+                        # GRBM_GUI_ACTIVE = cycles the GPU was busy during the dispatch (summed over the 8 XCDs when it exceeds what one
+                        # clock domain can tick in the duration): the measured shader clock, and the VALU busy fraction against it
+                        units = 8 if gui / (dur_us * 1e-6) > 3.0e9 else 1
+                        clk = gui / units / (dur_us * 1e-6)
+                        valu.update({"GRBM_GUI_ACTIVE_per_launch": gui, "measured_clock_GHz": clk / 1e9,
+                                     "busy_fraction_at_measured_clock": act * 4.0 / (1024 * (gui / units))})
+                    else:
+                        valu["busy_fraction_note"] = "no GRBM_GUI_ACTIVE in this counter pass: the clock during the kernel is unknown, no busy fraction is derived"
             except Exception:
                 pass
             roofline = {"bound": "hbm", "kernel": kern.rstrip("<"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -571,6 +585,12 @@ def main():
             "pipeline": {"algorithmic_bytes_per_view": total_bytes,
                          "achieved_GBps_end_to_end": total_bytes * VPS / (ms_per_step * 1e-3) / 1e9 if world == 1 else None,
                          "frac_of_hbm_peak_end_to_end": total_bytes * VPS / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
+                         "frac_of_hbm_peak_note": "view-equivalent: SURVEY 8(d)'s per-view bytes x views per step; a multi-view pass reads the "
+                                                  "236 B/splat of parameters once for all its views, so the bytes actually moved are fewer — "
+                                                  "see counter_bytes_per_step",
+                         "counter_bytes_per_step": counter_bytes_step if roofline is not None else None,
+                         "frac_of_hbm_peak_by_counters": (counter_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                                                         if (roofline is not None and counter_bytes_step) else None,
                          "sum_of_stage_ms": raster_ms, "stages": stage_table},
         }
         # compute-side figure of SURVEY.md §8(d): pixel-splat interactions I = sum over tiles of (list entries walked before all 256
@@ -604,8 +624,11 @@ def main():
                     err = np.abs(ih[:, ok] - ref["img"][:, ok]) / (1e-4 * np.abs(ref["img"][:, ok]) + 1e-6)
                     par = {"view": 0, "num_rendered_equal": int(rast1.get_num_rendered()) == ref["num_rendered"],
                            "rgb_max_err_over_tol(1e-4 rel + 1e-6)": float(err.max()), "fragile_pixels": int(ref["fragile"].sum())}
-                    for k_ in ("pos", "sh0", "opacity", "scale", "rot"):
-                        a, b = g1[k_].double().cpu().numpy(), np.asarray(ref["grads"][k_], np.float64)
+                    for k_ in ("pos", "sh0", "shN", "opacity", "scale", "rot"):
+                        gk = g1[k_]
+                        if k_ == "shN" and tiled:           # back to the reference's [n][45] rows
+                            gk = rast1.shn_relayout(gk.contiguous().view(-1), n, to_tiled=False).view(n, 15, 3)
+                        a, b = gk.double().cpu().numpy().reshape(-1), np.asarray(ref["grads"][k_], np.float64).reshape(-1)
                         par["grad_rel_l2_" + k_] = float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
                     rec["parity_vs_oracle"] = par
                 except Exception as e:      # noqa: BLE001

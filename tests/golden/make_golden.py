@@ -8,6 +8,8 @@ by (a) the C++ oracle in fp32 and fp64 and (b) the independent dense PyTorch-aut
 (dense_ref.py, fp64); (a) and (b) must agree (image 1e-9, gradients 1e-7 relative in fp64) before anything
 is written. The fixture stores the fp64 oracle's image and gradients (as float32 for size), integer
 bin checksums of the fp32 oracle (radii, tiles_touched, sorted keys / values, ranges) and n_contrib.
+`make_golden.py edges` regenerates only the edge-case fixture (E_edges.npz: the scenes of edge_scenes.py — everything culled, a splat
+on a tile corner, one covering the image, a saturating stack with tile lists > 256, a tile with > 65 536 entries).
 """
 import hashlib
 import json
@@ -87,10 +89,65 @@ def build(name):
     return meta
 
 
+def build_edges():
+    """The edge cases of SURVEY.md §8(c) (edge_scenes.py: explicit parameter arrays): fp64 oracle outputs, pinned for the scenes the dense
+    formulation can hold (E1-E3) by the same cross-check as the seeded goldens. One file, arrays prefixed with the scene name."""
+    import edge_scenes as es
+    cam = es.camera()
+    arrays, metas = {}, {}
+    for name, P in es.scenes(cam).items():
+        n = P["pos"].shape[0]
+        o32, o64 = Oracle(np.float32), Oracle(np.float64)
+        img32 = o32.forward(P, cam, sh_degree=es.DEG)
+        img64 = o64.forward(P, cam, sh_degree=es.DEG)
+        dL = es.upstream(img64.shape)
+        g64 = o64.backward(dL.astype(np.float64))
+        rng_ = o32.get("ranges")
+        meta = {"n": n, "T": int(o32.get("vals").size), "visible": int((o32.get("radii") > 0).sum()),
+                "max_tile_list": int((rng_[:, 1].astype(np.int64) - rng_[:, 0]).max()) if rng_.size else 0,
+                "min_final_T": float(o32.get("final_T").min()),
+                "sha_radii": sha(o32.get("radii")), "sha_tiles_touched": sha(o32.get("tiles_touched")),
+                "sha_keys": sha(o32.get("keys")), "sha_vals": sha(o32.get("vals")), "sha_ranges": sha(o32.get("ranges")),
+                "fragile_px": int((o32.get("fragile").astype(bool) | o64.get("fragile").astype(bool)).sum()),
+                "img_l2": float(np.linalg.norm(img64)), "grad_l2": {k: float(np.linalg.norm(g64[k])) for k in KEYS}}
+        if n <= 2000:
+            import torch
+            import dense_ref
+            img_t, leaves = dense_ref.render(P, cam, sh_degree=es.DEG, antialias=False)
+            if img_t.requires_grad:              # (an image no splat reaches depends on no parameter)
+                (img_t * torch.tensor(dL, dtype=torch.float64)).sum().backward()
+            ok = ~o64.get("fragile").astype(bool)
+            d_img = np.abs(img_t.detach().numpy() - img64)[:, ok].max() if n else 0.0
+            assert d_img < 1e-9, f"{name}: dense torch vs oracle image differ by {d_img}"
+            meta["dense_vs_oracle_img_maxabs"] = float(d_img)
+            for k in KEYS:
+                gt = (leaves[k].grad.numpy() if leaves[k].grad is not None else np.zeros(g64[k].shape)).reshape(g64[k].shape)
+                rel = np.abs(gt - g64[k]).max() / (np.abs(g64[k]).max() + 1e-300)
+                assert rel < 1e-7, f"{name}: dense torch vs oracle grad {k} differ by {rel} of max"
+                meta.setdefault("dense_vs_oracle_grad_rel", {})[k] = float(rel)
+        arrays[name + "/img"] = img64.astype(np.float32)
+        arrays[name + "/n_contrib"] = o32.get("n_contrib")
+        arrays[name + "/fragile"] = np.packbits(o32.get("fragile").astype(bool) | o64.get("fragile").astype(bool))
+        if n <= 2000:
+            for k in KEYS:
+                arrays[name + "/g_" + k] = g64[k].astype(np.float32)
+        else:                       # large scene: every 97th row
+            for k in KEYS:
+                arrays[name + "/g_" + k + "_rows97"] = g64[k][::97].astype(np.float32)
+        metas[name] = meta
+        print(name, "ok", {k: meta[k] for k in ("T", "visible", "max_tile_list", "min_final_T", "fragile_px")})
+    np.savez_compressed(os.path.join(HERE, "E_edges.npz"), **arrays)
+    return metas
+
+
 if __name__ == "__main__":
-    manifest = {}
-    for name in FIXTURES:
-        manifest[name] = build(name)
-        print(name, "ok", {k: v for k, v in manifest[name].items() if k in ("T", "visible", "dense_vs_oracle_img_maxabs")})
-    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+    only_edges = len(sys.argv) > 1 and sys.argv[1] == "edges"
+    mpath = os.path.join(HERE, "manifest.json")
+    manifest = json.load(open(mpath)) if only_edges else {}
+    if not only_edges:
+        for name in FIXTURES:
+            manifest[name] = build(name)
+            print(name, "ok", {k: v for k, v in manifest[name].items() if k in ("T", "visible", "dense_vs_oracle_img_maxabs")})
+    manifest["_edges"] = build_edges()
+    with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -1,5 +1,6 @@
-"""Full-size configs on the GPU (BASELINE.json C3 and the C5 stress shape) checked through size-independent properties
-(the oracle is too slow to run at these sizes inside the GPU suite; C3 parity against the oracle: tests/diag_gpu_vs_oracle.py and the `parity_vs_oracle` field of bench.py):
+"""Full-size configs on the GPU (BASELINE.json C3 and the C5 stress shape): one view of each against the oracle with the same bars as
+the small configurations (test_full_size_parity_vs_oracle: integers and preprocess floats bit-exact, rgb 1e-4 off fragile pixels,
+all six gradient groups in both gradient modes against the fp64 oracle), and size-independent properties:
   * per-tile lists are sorted by (depth, splat id) and ranges tile the instance list exactly,
   * sum(tiles_touched) == T, every instance's tile lies inside its splat's rect,
   * compositing invariants: 0 <= final_T <= 1, n_contrib <= list length, image finite,
@@ -11,6 +12,22 @@ import pytest
 import divshot_amd as dv
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,n,W,H,soff", [("C3", 1_000_000, 1920, 1080, 0.0), ("C5_shape", 5_000_000, 3840, 2160, -0.6931472)])
+def test_full_size_parity_vs_oracle(gpu_device, oracle_mod, name, n, W, H, soff):
+    """BASELINE configs C3 and C5's shape, one view each (camera 3 of 8), every stage against the OpenMP oracle (about 2 s / 10 s per
+    forward + backward on the GPU box's host cores): the full bar of test_pipeline_parity with the default A8 kernel and the round-2 one."""
+    from divshot_amd.raster import Rasterizer
+    from test_gpu_parity import check_pipeline_parity
+    r = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    r.keep_intermediates(True)
+    try:
+        rep = check_pipeline_parity(r, oracle_mod, name + "_full", (n, W, H, 3, 1, soff, False, (0.0, 0.0, 0.0)), variants=("tr", "blocks"),
+                                    n_cams=8, cam_index=3)
+    finally:
+        r.close()
+    assert rep["T"] > n and rep["tainted_splat_fraction"] < 0.10
 
 
 @pytest.mark.parametrize("name,n,W,H,soff", [("C3", 1_000_000, 1920, 1080, 0.0), ("C5_shape", 5_000_000, 3840, 2160, -0.6931472)])

@@ -54,7 +54,7 @@ def rast(gpu_device):
     r.close()
 
 
-def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
+def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True, variants=None):
     """forward once; backward for every (grad_mode, A8 kernel variant) combination on the same upstream gradient"""
     import torch
     from divshot_amd.raster import params_to_device
@@ -75,7 +75,7 @@ def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True):
     dL = torch.from_numpy((img_h - tgt) / tgt[0].size).to(rast.tdev)
     runs = {}
     for mode in (0, 1):
-        for variant in BWD_VARIANTS:
+        for variant in (variants or BWD_VARIANTS):
             rast.set_backward_variant(variant)
             rast._opts.grad_mode = mode
             grads = rast.backward(dL, want_mean2d=True)
@@ -92,9 +92,15 @@ REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_pipeline_parity(rast, oracle_mod, name):
-    n, W, H, deg, seed, soff, aa, bg = CONFIGS[name]
-    spec, P, cam, tgt = scene(n, W, H, deg, seed, scale_offset=soff, bg=bg)
-    img, saved, keys, runs, dL = _run_gpu(rast, P, cam, tgt, deg, aa)
+    check_pipeline_parity(rast, oracle_mod, name, CONFIGS[name])
+
+
+def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, cam_index=0):
+    """Every stage of one view against the oracle (also used at full size by tests/test_gpu_large.py)."""
+    n, W, H, deg, seed, soff, aa, bg = cfg
+    variants = variants or BWD_VARIANTS
+    spec, P, cam, tgt = scene(n, W, H, deg, seed, n_cams=n_cams, cam_index=cam_index, scale_offset=soff, bg=bg)
+    img, saved, keys, runs, dL = _run_gpu(rast, P, cam, tgt, deg, aa, variants=variants)
 
     o = oracle_mod.Oracle(np.float32)
     ref_img = o.forward(P, cam, sh_degree=deg, antialias=aa)
@@ -137,13 +143,19 @@ def test_pipeline_parity(rast, oracle_mod, name):
     tainted = np.zeros(n, bool)
     fy, fx = np.where(frag_any)
     m2, rad, co = saved["mean2d"].astype(np.float64), saved["radii"], saved["conic_opacity"].astype(np.float64)
+    tiles_x = (W + 15) // 16
+    vals_l, ranges_l = saved["vals"], saved["ranges"].astype(np.int64)
     for x, y in zip(fx, fy):
         # a flipped decision at (x, y) moves the gradient of every splat that can contribute there (alpha >= 1/255 up to the
-        # fragility margin) — not of splats whose 3-sigma box merely covers the pixel
-        ddx, ddy = m2[:, 0] - x, m2[:, 1] - y
-        power = -0.5 * (co[:, 0] * ddx * ddx + co[:, 2] * ddy * ddy) - co[:, 1] * ddx * ddy
-        alpha = np.minimum(0.99, co[:, 3] * np.exp(np.minimum(power, 0.0)))
-        tainted |= (np.abs(ddx) <= rad) & (np.abs(ddy) <= rad) & (rad > 0) & (power <= 1e-6) & (alpha >= (1.0 / 255.0) * (1 - 1e-3))
+        # fragility margin) — not of splats whose 3-sigma box merely covers the pixel. Candidates: the pixel's tile list (a splat
+        # that reaches the pixel is binned into its tile).
+        t_ = (y // 16) * tiles_x + x // 16
+        cand = np.unique(vals_l[ranges_l[t_, 0]:ranges_l[t_, 1]])
+        ddx, ddy = m2[cand, 0] - x, m2[cand, 1] - y
+        power = -0.5 * (co[cand, 0] * ddx * ddx + co[cand, 2] * ddy * ddy) - co[cand, 1] * ddx * ddy
+        alpha = np.minimum(0.99, co[cand, 3] * np.exp(np.minimum(power, 0.0)))
+        hit = (np.abs(ddx) <= rad[cand]) & (np.abs(ddy) <= rad[cand]) & (rad[cand] > 0) & (power <= 1e-6) & (alpha >= (1.0 / 255.0) * (1 - 1e-3))
+        tainted[cand[hit]] = True
     # the tainted set is the carve-out of this test: bounded for every config and written to the report
     if not name.startswith(("dense", "rnd")):      # huge splats: one fragile pixel taints everything that covers it
         assert tainted.mean() < 0.10, tainted.mean()
@@ -190,7 +202,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
             # fp64 binned differently somewhere (a radius at an integer boundary): the fp32 oracle is the strict reference
             ref64, inter64 = ref32, inter32
         oracle_grads[mode] = ref64
-        for variant in BWD_VARIANTS:
+        for variant in variants:
             grads, inter = runs[(mode, variant)]
             rec = report["runs"].setdefault(f"grad_mode{mode}/{variant}", {})
             tag = f"[mode {mode}, {variant}] "
@@ -212,6 +224,7 @@ def test_pipeline_parity(rast, oracle_mod, name):
     except OSError:
         pass
     print("parity report:", json.dumps({k: report[k] for k in ("config", "tainted_splat_fraction", "fragile_pixel_fraction", "lineage_vs_true_rel_l2")}))
+    return report
 
 
 def test_accumulate_two_views(rast, oracle_mod):

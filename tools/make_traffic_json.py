@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Build profiles/rNN_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc.sh + rocpd_summary.py).
-usage: tools/make_traffic_json.py pmc_fetch.txt pmc_write.txt > profiles/rNN_traffic.json"""
+usage: tools/make_traffic_json.py pmc_fetch.txt pmc_write.txt [steps_of_the_profiled_command] > profiles/rNN_traffic.json
+With the step count of the profiled bench command (tools/pmc.sh: 3 timed + 1 warm-up = 4) every kernel also gets launches_per_step
+(= calls / steps; kernels launched fewer times than there were steps are set-up work) and the file a counter_bytes_per_step total."""
 import json
 import re
 import sys
@@ -15,8 +17,20 @@ def parse(path, counter):
     return out
 
 
+def calls(path):
+    """kernel -> launches, from the kernel-trace table of the same summary file"""
+    out = {}
+    for line in open(path):
+        m = re.match(r"\s+(\S.*?)\s+(\d+)\s+[0-9.]+\s+[0-9.]+\s+[0-9.]+\s+[0-9.]+\s+[0-9.]+\s+\d+\s+\d+\s+\d+", line)
+        if m:
+            out[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
 def main():
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    ncalls = calls(sys.argv[1])
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
@@ -24,12 +38,19 @@ def main():
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         kernels[k] = {"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
                       "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+        if steps and ncalls.get(k, 0) >= steps:
+            kernels[k]["launches_per_step"] = ncalls[k] / steps
     how = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh) on bench.py's default workload, C3, "
            "1x MI355X. Units are KB (x1024). Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE "
            "reports half the bytes of wide coalesced reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibrated on "
            "k_preprocess_fwd (236 B read per splat). The factor 2 is NOT calibrated for the narrow gathers of the composite kernels "
            "(their figure is an upper bound), the counters include Infinity-Cache hits, and cross-XCD fp32 atomics are counted as writes.")
-    json.dump({"_how": how, "workload": "C3", "views_per_launch": 8, "kernels": kernels}, sys.stdout, indent=1)
+    out = {"_how": how, "workload": "C3", "views_per_launch": 8, "kernels": kernels}
+    if steps:
+        out["steps_of_profiled_command"] = steps
+        out["counter_bytes_per_step"] = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_per_step"] for v in kernels.values()
+                                                if "launches_per_step" in v))
+    json.dump(out, sys.stdout, indent=1)
     print()
 
 
