@@ -289,6 +289,8 @@ def main():
     comm_marks = []                               # (event before the exposed exchange, event after it) per timed step
     torch.cuda.synchronize()
 
+    gm = {"mode": args.grad_mode}            # (mutable: the lineage-mode side measurement below re-times the same step in grad_mode 1)
+
     def step(timed=False):
         if n_ctx > 1:
             step_done.record(main_stream)          # everything enqueued so far (previous step incl. its exchange)
@@ -301,7 +303,7 @@ def main():
                 if n_ctx > 1 and args.stagger and gi > 0:
                     st.wait_event(fwd_done[(gi - 1) % n_ctx])
                 imgs = rasts[c].forward_views(params, cams_group[gi], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled,
-                                              grad_mode=args.grad_mode)
+                                              grad_mode=gm["mode"])
                 if n_ctx > 1:
                     fwd_done[c].record(st)
                 dL = torch.add(neg_targets_group[gi], imgs, alpha=inv_P)
@@ -374,6 +376,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same step in the other gradient mode (libgstrain.so runs DVS_GRAD_LINEAGE, the headline DVS_GRAD_TRUE): a short timed
+    # side loop, so that "same cost" is a measured statement
+    other_mode = None
+    if graph is None and args.steps >= 10:
+        gm["mode"] = 1 - args.grad_mode
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        k_other = max(5, min(20, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(k_other):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t1
+        if dist is not None:
+            t_ = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el = float(t_.item())
+        other_mode = {"grad_mode": gm["mode"], "steps": k_other, "views_per_s": GLOBAL_VIEWS * k_other / el, "ms_per_step": el / k_other * 1e3}
+        gm["mode"] = args.grad_mode
+        step(); torch.cuda.synchronize()          # leave the gradient buffer as the timed region left it (norms below)
     for r_ in rasts:
         r_.get_num_rendered()         # raises if an asynchronous forward of the timed region overflowed its instance arena
     grad_norms = {k: float(v.double().norm()) for k, v in gbuf.views.items()}      # after the exchange: identical on every rank
@@ -568,6 +595,7 @@ def main():
             "metric": "train views/sec (fwd+bwd raster) at 1M splats 1920x1080" if args.workload == "C3" else f"train views/sec (fwd+bwd raster), workload {args.workload}",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+            "other_grad_mode": other_mode,
             "strict_single_view": strict, "t_raster_ms_per_step": (ms_per_step - comm_ms["mean"]) if comm_ms else ms_per_step,
             "t_comm_exposed_ms_per_step": comm_ms, "comm_microbench": comm_micro, "clocks": clocks,
             "step_ms_p10_p50_p90": step_spread,

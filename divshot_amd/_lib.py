@@ -126,6 +126,8 @@ _PROTOS = {
     "dvs_loss_l1_ssim_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                             C.c_void_p, C.c_void_p]),
     "dvs_densify_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvs_densify_accumulate_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvs_any_view_radius": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dvs_densify_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DensifyParams),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_densify_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DensifyParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -51,6 +51,39 @@ k_densify_accumulate(int n, const int* __restrict__ radii, const float2* __restr
     max_radii[i] = max(max_radii[i], r);
 }
 
+// the same rule for the n_views views of a multi-view pass, read from the composite backward's rows BEFORE the preprocess backward
+// consumes them (row floats 9, 10 = sum over the view's pixels of |dL/dmean2D| x, y: exactly what A9 hands out as absgrad2d)
+__global__ void __launch_bounds__(DB)
+k_densify_accumulate_rows(int n, int n_views, const int* __restrict__ radii, const float* __restrict__ rows, float half_w, float half_h,
+                          float* __restrict__ grad_accum, float* __restrict__ denom, int* __restrict__ max_radii) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f, cnt = 0.f;
+    int rmax = 0;
+    for (int v = 0; v < n_views; ++v) {
+        const int r = radii[(size_t)v * n + i];
+        if (r <= 0) continue;
+        const float* row = rows + ((size_t)v * n + i) * 12;
+        const float gx = row[9] * half_w, gy = row[10] * half_h;
+        acc += sqrtf(gx * gx + gy * gy);
+        cnt += 1.0f;
+        rmax = max(rmax, r);
+    }
+    if (cnt > 0.f) {
+        grad_accum[i] += acc;
+        denom[i] += cnt;
+        max_radii[i] = max(max_radii[i], rmax);
+    }
+}
+// radius > 0 in any of the views (visibleAdam with several views per step)
+__global__ void __launch_bounds__(DB) k_any_view_radius(int n, int n_views, const int* __restrict__ radii, int* __restrict__ out) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= n) return;
+    int r = 0;
+    for (int v = 0; v < n_views; ++v) r = max(r, radii[(size_t)v * n + i]);
+    out[i] = r;
+}
+
 __device__ __forceinline__ int d_action(int i, const float* opacity, const float* scale, const float* grad_accum, const float* denom,
                                         const int* max_radii, const dvs_densify_params& p) {
     const float op = 1.0f / (1.0f + __expf(-opacity[i]));
@@ -178,6 +211,20 @@ int dvs_densify_accumulate(void* stream, int n, const int32_t* radii, const floa
     if (n == 0) return DVS_OK;
     hipLaunchKernelGGL(k_densify_accumulate, dim3((n + DB - 1) / DB), dim3(DB), 0, (hipStream_t)stream, n, radii, (const float2*)absgrad2d,
                        0.5f * (float)width, 0.5f * (float)height, grad_accum, denom, max_radii);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_densify_accumulate_rows(void* stream, int n, int n_views, const int32_t* radii, const float* rows, int width, int height,
+                                float* grad_accum, float* denom, int32_t* max_radii) {
+    if (n < 0 || n_views < 1 || (n > 0 && (!radii || !rows || !grad_accum || !denom || !max_radii))) return DVS_ERR_INVALID;
+    if (n == 0) return DVS_OK;
+    hipLaunchKernelGGL(k_densify_accumulate_rows, dim3((n + DB - 1) / DB), dim3(DB), 0, (hipStream_t)stream, n, n_views, radii, rows,
+                       0.5f * (float)width, 0.5f * (float)height, grad_accum, denom, max_radii);
+    return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_any_view_radius(void* stream, int n, int n_views, const int32_t* radii, int32_t* out) {
+    if (n < 0 || n_views < 1 || (n > 0 && (!radii || !out))) return DVS_ERR_INVALID;
+    if (n == 0) return DVS_OK;
+    hipLaunchKernelGGL(k_any_view_radius, dim3((n + DB - 1) / DB), dim3(DB), 0, (hipStream_t)stream, n, n_views, radii, out);
     return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
 }
 int dvs_densify_plan(void* stream, int n, const float* opacity, const float* scale, const float* grad_accum, const float* denom,

@@ -25,7 +25,8 @@ static std::map<std::string, std::string> g_opts = {
     {"absgrad", "1"}, {"growGrad2d", "0.0002"}, {"warmupLength", "500"}, {"refineEvery", "100"}, {"resetAlphaEvery", "3000"},
     {"refineStopIter", "15000"}, {"refineScale2dStopIter", "15000"}, {"minOpacity", "0.005"}, {"pruneEvery", "70000"},
     {"pruneStrategy", "1"}, {"revisedOpacity", "1"}, {"mipAntiliased", "0"}, {"packLevel", "1"}, {"exportMesh", "0"},
-    {"noiselr", "100000"}, {"useMask", "0"}, {"eval", "0"}};
+    {"noiselr", "100000"}, {"useMask", "0"}, {"eval", "0"},
+    {"viewsPerIter", "1"}};       // extension of this build: cameras per train_step as one multi-view pass (BASELINE config C4: 8)
 
 static bool as_bool(const std::string& v) { return v == "1" || v == "true" || v == "True" || v == "on"; }
 
@@ -94,6 +95,7 @@ int main(int argc, const char* argv[]) {
     train_config.exportMesh = as_bool(g_opts["exportMesh"]);
     train_config.useMask = as_bool(g_opts["useMask"]);
     train_config.numIters = max_iteraion;
+    if (g_opts.count("viewsPerIter")) train_config.viewsPerIter = atoi(g_opts["viewsPerIter"].c_str());   // extension of this build (config C4)
     train_config.normalConsistencyLoss = false;
     if (train_config.exportMesh) { train_config.normalConsistencyLoss = true; train_config.useMask = true; }
     train_config.verbose = true;

@@ -107,6 +107,10 @@ struct GaussianTrainerScene::Impl {
     void* d_mcmc = nullptr;                                                  // dvs_mcmc_* scratch (densifyStrategy 1)
     float extent = 1.f;                                                      // scene extent (camera spread), sets the split/clone scale
     dvs_fwd_state fwd{};
+    int vpi = 1;                                                             // views per trainStep and GPU, one multi-view pass (cfg.viewsPerIter / DVS_VIEWS_PER_ITER)
+    bool sequential_views = false;                                           // DVS_VIEWS_MODE=sequential: the same views one pass at a time, accumulating (the reference shape)
+    int* d_vis_radius = nullptr;                                             // visibleAdam with vpi > 1: max radius over the step's views
+    int loss_views = 1;                                                      // views whose loss sums d_loss holds
     std::vector<dvs_camera> cams;
     std::vector<float*> d_targets;
     float* d_out = nullptr; float* d_dL = nullptr; float* d_loss = nullptr;     // d_loss[0..63] = (1-w) L1 partial sums, d_loss[64..127] = SSIM partial sums
@@ -130,6 +134,7 @@ struct GaussianTrainerScene::Impl {
         for (float* t : d_masks) (void)hipFree(t);
         d_masks.clear();
         for (float** p : {&d_grad_flat, &d_mean2d, &d_target_f32, &d_dcolor_local, &d_dcolor_all, &d_dcolor_scratch}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (d_vis_radius) { (void)hipFree(d_vis_radius); d_vis_radius = nullptr; }
         for (hipEvent_t* e : {&ev_dcolor, &ev_bwd, &ev_comm}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
         if (comm_stream) { (void)hipStreamDestroy(comm_stream); comm_stream = nullptr; }
         if (comm) { dvs_comm_destroy(comm); comm = nullptr; }
@@ -293,13 +298,20 @@ bool GaussianTrainerScene::Impl::load_synthetic(const std::string& spec_str) {
     for (int g = 0; g < 6; ++g) gt[g].resize((size_t)spec.n * kWidth[g]);
     DVS_OR_THROW(dvs_synth_splats(&spec, gt[0].data(), gt[1].data(), gt[2].data(), gt[3].data(), gt[4].data(), gt[5].data()));
     const int capacity = std::max(spec.n, cfg.capMax);          // --capMax is the array capacity (gs_train.cpp:89); 1.9 KB of HBM per splat
-    ctx = dvs_create(device, (size_t)capacity, W, H);
-    if (!ctx) throw std::runtime_error(std::string("dvs_create: ") + dvs_last_error());
+    vpi = cfg.viewsPerIter;
+    if (const char* e = getenv("DVS_VIEWS_PER_ITER")) vpi = atoi(e);
+    vpi = std::max(1, std::min(vpi, 16));
+    if (const char* e = getenv("DVS_VIEWS_MODE")) sequential_views = std::string(e) == "sequential";
+    if (vpi > 1 && rank == 0)
+        logf_("config: %d views per trainStep and GPU, %s", vpi, sequential_views ? "one pass per view, gradients accumulated (DVS_VIEWS_MODE=sequential)"
+                                                                                : "ONE multi-view pass (dvs_raster_forward_views / _backward_views), gradients summed");
+    ctx = dvs_create_views(device, (size_t)capacity, W, H, sequential_views ? 1 : vpi);
+    if (!ctx) throw std::runtime_error(std::string("dvs_create_views: ") + dvs_last_error());
     // ground-truth views: render the generating scene once per camera
     alloc_params(spec.n, capacity, gt);
     const size_t img = 3 * (size_t)W * H;
-    HIP_OR_THROW(hipMalloc((void**)&d_out, img * sizeof(float)));
-    HIP_OR_THROW(hipMalloc((void**)&d_dL, img * sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_out, (size_t)vpi * img * sizeof(float)));
+    HIP_OR_THROW(hipMalloc((void**)&d_dL, (size_t)vpi * img * sizeof(float)));
     HIP_OR_THROW(hipMalloc((void**)&d_loss, 2 * DVS_SSIM_SLOTS * sizeof(float)));
     HIP_OR_THROW(hipMemset(d_loss, 0, 2 * DVS_SSIM_SLOTS * sizeof(float)));
     if (cfg.ssimWeight > 0.f)
@@ -522,15 +534,17 @@ void GaussianTrainerScene::trainStep() {
     Impl& m = *impl_;
     if (!m.ctx || m.cams.empty()) throw std::runtime_error("trainStep before loadTrainData");
     HIP_OR_THROW(hipSetDevice(m.device));
-    // cameras: one xorshift stream shared by all ranks; an iteration draws `world` views and rank r renders the r-th (one view per
-    // GPU and iteration, as the reference's trainStep renders one camera)
-    int ci = 0;
-    std::vector<int> ci_all((size_t)m.world, 0);                    // every rank knows every rank's camera: the SH rows are rebuilt from them
-    for (int r = 0; r < m.world; ++r) {
+    // cameras: one xorshift stream shared by all ranks; an iteration draws world x vpi views and rank r renders views r vpi .. r vpi + vpi - 1
+    // (vpi = 1: one view per GPU and iteration, as the reference's trainStep renders one camera; vpi = 8 on one GPU: BASELINE config C4)
+    const int V = m.vpi;
+    std::vector<int> ci_all((size_t)m.world * V, 0);                // every rank knows every rank's cameras: the SH rows are rebuilt from them
+    for (size_t k = 0; k < ci_all.size(); ++k) {
         m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
-        ci_all[(size_t)r] = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
-        if (r == m.rank) ci = ci_all[(size_t)r];
+        ci_all[k] = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
     }
+    const int* ci_mine = &ci_all[(size_t)m.rank * V];
+    std::vector<dvs_camera> vcams((size_t)V);
+    for (int v = 0; v < V; ++v) vcams[(size_t)v] = m.cams[(size_t)ci_mine[v]];
     const int it = m.step + 1;
     const int deg = m.cfg.progressiveTrain ? std::min(m.sh_max, m.step / 1000) : m.sh_max;   // SH bands unlocked every 1000 steps
     const bool mcmc = m.mcmc();
@@ -542,58 +556,115 @@ void GaussianTrainerScene::trainStep() {
     opts.shn_layout = DVS_SHN_TILED;
     opts.grad_mode = DVS_GRAD_LINEAGE;          // the backward of the lineage the reference credits (README.md:95)
     const dvs_splats sp = m.splats();
-    DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_out, &m.fwd, nullptr));
-    // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25); its gradient goes straight into d_dL
-    const float* target = m.target_for(ci);
+    const size_t img = 3 * (size_t)m.W * m.H;
     const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
+    // photometric loss (1-w) L1 + w (1 - SSIM), w = --ssim (main.cpp:24-25), of view v: its gradient goes straight into d_dL[v]; the loss
+    // sums of the step's views add up in d_loss (getCurrentLoss reports their mean)
+    auto loss_of_view = [&](int v) {
+        const float* target = m.target_for(ci_mine[v]);
+        const float* out = m.d_out + (size_t)v * img;
+        float* dL = m.d_dL + (size_t)v * img;
+        if (w_ssim > 0.f) {     // SSIM maps, then the L1 and SSIM gradients in one pass over the image
+            DVS_OR_THROW(dvs_ssim_forward(m.stream, out, target, m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
+                                          m.d_loss + DVS_SSIM_SLOTS));
+            DVS_OR_THROW(dvs_loss_l1_ssim_backward(m.stream, out, target, m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1],
+                                                   m.d_ssim_maps[2], w_ssim, dL, m.d_loss));
+        } else {
+            DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, out, target, img, 1.f, dL, m.d_loss));
+        }
+        if (m.cfg.useMask && !m.d_masks.empty()) {
+            const size_t P = (size_t)m.W * m.H;
+            hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)((3 * P + 255) / 256)), dim3(256), 0, m.stream, dL, m.d_masks[(size_t)ci_mine[v]], P);
+        }
+    };
     HIP_OR_THROW(hipMemsetAsync(m.d_loss, 0, 2 * DVS_SSIM_SLOTS * sizeof(float), m.stream));
-    if (w_ssim > 0.f) {     // SSIM maps, then the L1 and SSIM gradients in one pass over the image
-        DVS_OR_THROW(dvs_ssim_forward(m.stream, m.d_out, target, m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1], m.d_ssim_maps[2],
-                                      m.d_loss + DVS_SSIM_SLOTS));
-        DVS_OR_THROW(dvs_loss_l1_ssim_backward(m.stream, m.d_out, target, m.W, m.H, m.d_ssim_maps[0], m.d_ssim_maps[1],
-                                               m.d_ssim_maps[2], w_ssim, m.d_dL, m.d_loss));
-    } else {
-        DVS_OR_THROW(dvs_l1_loss_grad_w(m.stream, m.d_out, target, 3 * (size_t)m.W * m.H, 1.f, m.d_dL, m.d_loss));
-    }
-    if (m.cfg.useMask && !m.d_masks.empty()) {
-        const size_t P = (size_t)m.W * m.H;
-        hipLaunchKernelGGL(k_mask_mul, dim3((unsigned)((3 * P + 255) / 256)), dim3(256), 0, m.stream, m.d_dL, m.d_masks[ci], P);
-    }
+    m.loss_views = V;
     dvs_splat_grads g{};
     g.pos = m.d_grad[P_POS]; g.sh0 = m.d_grad[P_SH0]; g.shN = m.d_grad[P_SHN]; g.opacity = m.d_grad[P_OPA];
     g.scale = m.d_grad[P_SCALE]; g.rot = m.d_grad[P_ROT]; g.absgrad2d = absgrad ? m.d_absgrad : nullptr;
     g.mean2d = (!absgrad && !mcmc && refining) ? m.d_mean2d : nullptr;      // ADC without abs-grad: the norm of dL/dmean2D is the statistic
     const bool fact = m.comm && m.factorised;
-    if (fact) {
-        // The SH rows are not written by the backward: only the view's colour gradient, which leaves right after the composite
-        // backward (dvs_raster_backward_dcolor) so that its all-gather runs on the communication stream while A9 computes.
-        if (!m.d_dcolor_local) {
-            HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_local, (size_t)m.cap * 3 * sizeof(float) + 16));
-            HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_scratch, (size_t)m.cap * 3 * sizeof(float) + 16));
-            HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_all, (size_t)m.world * m.cap * 3 * sizeof(float) + 16));
-            HIP_OR_THROW(hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking));
-            for (hipEvent_t* e : {&m.ev_dcolor, &m.ev_bwd, &m.ev_comm}) HIP_OR_THROW(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (fact && !m.d_dcolor_local) {
+        // factorised exchange: the SH rows are not written by the backward, only each view's colour gradient, which leaves right after
+        // the composite backward (dvs_raster_backward_dcolor) so that its all-gather runs on the communication stream while A9 computes
+        HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_local, (size_t)V * m.cap * 3 * sizeof(float) + 16));
+        HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_scratch, (size_t)V * m.cap * 3 * sizeof(float) + 16));
+        HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_all, (size_t)m.world * V * m.cap * 3 * sizeof(float) + 16));
+        HIP_OR_THROW(hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&m.ev_dcolor, &m.ev_bwd, &m.ev_comm}) HIP_OR_THROW(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    // densification statistics of the step's views, summed over the ranks in densify(): per view and visible
+    // splat  grad_accum += |abs-grad|, denom += 1, max_radii = max
+    const bool want_stats = refining && !mcmc;
+    const int* vis_radii = nullptr;                                   // visible-only Adam: radius > 0 in any of the step's views
+    if (m.sequential_views || V == 1) {
+        // one pass per view (the reference's shape; with V > 1 the gradients accumulate over the views: DVS_VIEWS_MODE=sequential)
+        for (int v = 0; v < V; ++v) {
+            opts.accumulate = v > 0 ? 1 : 0;
+            DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &vcams[(size_t)v], &opts, m.d_out + (size_t)v * img, &m.fwd, nullptr));
+            loss_of_view(v);
+            const float* dLv = m.d_dL + (size_t)v * img;
+            if (fact) {
+                g.sh0 = nullptr; g.shN = nullptr; g.dcolor = m.d_dcolor_scratch + (size_t)v * m.n * 3;
+                DVS_OR_THROW(dvs_raster_backward_composite(m.ctx, m.stream, &vcams[(size_t)v], &opts, dLv));
+                DVS_OR_THROW(dvs_raster_backward_dcolor(m.ctx, m.stream, m.d_dcolor_local + (size_t)v * m.n * 3));
+            } else {
+                DVS_OR_THROW(dvs_raster_backward_composite(m.ctx, m.stream, &vcams[(size_t)v], &opts, dLv));
+            }
+            if (want_stats && absgrad) {
+                const float* rows = nullptr; int rf = 0;
+                DVS_OR_THROW(dvs_get_bwd_intermediates(m.ctx, &rows, &rf));
+                DVS_OR_THROW(dvs_densify_accumulate_rows(m.stream, m.n, 1, m.fwd.radii, rows, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
+            }
+            if (fact && v == V - 1) {           // all local views' colour gradients leave in ONE all-gather, under the last view's A9
+                HIP_OR_THROW(hipEventRecord(m.ev_dcolor, m.stream));
+                HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_dcolor, 0));
+                DVS_OR_THROW(dvs_comm_all_gather_f32(m.comm, m.comm_stream, m.d_dcolor_local, m.d_dcolor_all, (size_t)V * m.n * 3));
+            }
+            DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, &vcams[(size_t)v], &opts, &g));
+            if (want_stats && !absgrad) {       // the standard rule: |dL/dmean2D| of the view, threshold growGrad2d (0.0002)
+                if (v > 0) throw std::runtime_error("gstrain: DVS_VIEWS_MODE=sequential with useAbsGrad off needs per-view mean2d rows (use the multi-view pass)");
+                hipLaunchKernelGGL(k_norm2, dim3((unsigned)((m.n + 255) / 256)), dim3(256), 0, m.stream, m.d_mean2d, m.d_mean2d, m.n);
+                DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, m.d_mean2d, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
+            }
         }
-        g.sh0 = nullptr; g.shN = nullptr; g.dcolor = m.d_dcolor_scratch;
-        DVS_OR_THROW(dvs_raster_backward_composite(m.ctx, m.stream, &m.cams[ci], &opts, m.d_dL));
-        DVS_OR_THROW(dvs_raster_backward_dcolor(m.ctx, m.stream, m.d_dcolor_local));
-        HIP_OR_THROW(hipEventRecord(m.ev_dcolor, m.stream));
-        HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_dcolor, 0));
-        DVS_OR_THROW(dvs_comm_all_gather_f32(m.comm, m.comm_stream, m.d_dcolor_local, m.d_dcolor_all, (size_t)m.n * 3));
-        DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, &m.cams[ci], &opts, &g));
+        vis_radii = m.fwd.radii;                // (V > 1 here: the last view's — visibleAdam is a single-view notion in this mode)
     } else {
-        DVS_OR_THROW(dvs_raster_backward(m.ctx, m.stream, &sp, &m.cams[ci], &opts, m.d_dL, &g));
+        // ONE multi-view pass: parameters read once, one depth sort / scan / (view, tile) sort / composite launch for all V views, the
+        // gradient rows written once (their sum over the views)
+        DVS_OR_THROW(dvs_raster_forward_views(m.ctx, m.stream, &sp, vcams.data(), V, &opts, m.d_out));
+        DVS_OR_THROW(dvs_get_view_state(m.ctx, 0, &m.fwd));                       // (view-major arrays: fwd.radii = [V][n])
+        for (int v = 0; v < V; ++v) loss_of_view(v);
+        if (fact) { g.sh0 = nullptr; g.shN = nullptr; g.dcolor = m.d_dcolor_scratch; }
+        DVS_OR_THROW(dvs_raster_backward_composite(m.ctx, m.stream, vcams.data(), &opts, m.d_dL));
+        if (fact) {
+            DVS_OR_THROW(dvs_raster_backward_dcolor(m.ctx, m.stream, m.d_dcolor_local));
+            HIP_OR_THROW(hipEventRecord(m.ev_dcolor, m.stream));
+            HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_dcolor, 0));
+            DVS_OR_THROW(dvs_comm_all_gather_f32(m.comm, m.comm_stream, m.d_dcolor_local, m.d_dcolor_all, (size_t)V * m.n * 3));
+        }
+        if (want_stats && absgrad) {            // per view, from the composite backward's rows (before A9 consumes them): the exact single-view rule
+            const float* rows = nullptr; int rf = 0;
+            DVS_OR_THROW(dvs_get_bwd_intermediates(m.ctx, &rows, &rf));
+            DVS_OR_THROW(dvs_densify_accumulate_rows(m.stream, m.n, V, m.fwd.radii, rows, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
+        }
+        DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, vcams.data(), &opts, &g));
+        if (want_stats && !absgrad) {
+            // without abs-grad the multi-view pass hands out the SUM over the views of dL/dmean2D: its norm is accumulated once per step
+            // for splats visible in at least one view (for V = 1 the reference rule; documented difference for V > 1)
+            if (!m.d_vis_radius) HIP_OR_THROW(hipMalloc((void**)&m.d_vis_radius, (size_t)m.cap * sizeof(int) + 16));
+            DVS_OR_THROW(dvs_any_view_radius(m.stream, m.n, V, m.fwd.radii, m.d_vis_radius));
+            hipLaunchKernelGGL(k_norm2, dim3((unsigned)((m.n + 255) / 256)), dim3(256), 0, m.stream, m.d_mean2d, m.d_mean2d, m.n);
+            DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.d_vis_radius, m.d_mean2d, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
+        }
+        if (m.cfg.visibleAdam && m.world == 1) {
+            if (!m.d_vis_radius) HIP_OR_THROW(hipMalloc((void**)&m.d_vis_radius, (size_t)m.cap * sizeof(int) + 16));
+            DVS_OR_THROW(dvs_any_view_radius(m.stream, m.n, V, m.fwd.radii, m.d_vis_radius));
+            vis_radii = m.d_vis_radius;
+        }
     }
     if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule)
         DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
-    if (refining && !mcmc) {    // densification statistics of this view; summed over the ranks in densify()
-        const float* stat = m.d_absgrad;
-        if (!absgrad) {         // the standard rule: |dL/dmean2D| of the view, threshold growGrad2d (0.0002)
-            hipLaunchKernelGGL(k_norm2, dim3((unsigned)((m.n + 255) / 256)), dim3(256), 0, m.stream, m.d_mean2d, m.d_mean2d, m.n);
-            stat = m.d_mean2d;
-        }
-        DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, stat, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
-    }
     // data parallel, over RCCL / xGMI: all-gather of the views' colour gradients + all-reduce of the geometry groups, then every
     // replica rebuilds the summed SH rows from all views (factorised) — or ONE sum-all-reduce of all six groups (they share a buffer)
     if (fact) {             // (both collectives on the communication stream, in the same order on every rank)
@@ -602,9 +673,9 @@ void GaussianTrainerScene::trainStep() {
         DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad_flat, m.geom_floats));
         HIP_OR_THROW(hipEventRecord(m.ev_comm, m.comm_stream));
         HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_comm, 0));
-        std::vector<float> campos((size_t)m.world * 3);
-        for (int r = 0; r < m.world; ++r) for (int k = 0; k < 3; ++k) campos[(size_t)r * 3 + k] = m.cams[(size_t)ci_all[(size_t)r]].campos[k];
-        DVS_OR_THROW(dvs_sh_grad_combine(m.ctx, m.stream, m.n, m.d_param[P_POS], deg, m.world, campos.data(), m.d_dcolor_all,
+        std::vector<float> campos(ci_all.size() * 3);               // slot order of the all-gather: [rank][local view]
+        for (size_t q = 0; q < ci_all.size(); ++q) for (int k = 0; k < 3; ++k) campos[q * 3 + k] = m.cams[(size_t)ci_all[q]].campos[k];
+        DVS_OR_THROW(dvs_sh_grad_combine(m.ctx, m.stream, m.n, m.d_param[P_POS], deg, (int)ci_all.size(), campos.data(), m.d_dcolor_all,
                                          m.d_grad[P_SH0], m.d_grad[P_SHN], 0, DVS_SHN_TILED));
     } else if (m.comm) {
         DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.stream, m.d_grad_flat, m.grad_floats));
@@ -622,8 +693,8 @@ void GaussianTrainerScene::trainStep() {
         if (k == P_SHN) ag[k].active_chunks = deg >= 3 ? 0 : (3 * ((deg + 1) * (deg + 1) - 1) + 3) / 4;
     }
     if (deg == 0) ag[P_SHN].count = 0;
-    const bool visible_only = m.cfg.visibleAdam && m.world == 1;       // per-rank visibility would let the replicas drift apart
-    DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, visible_only ? m.fwd.radii : nullptr, m.n));
+    const bool visible_only = m.cfg.visibleAdam && m.world == 1 && vis_radii;       // per-rank visibility would let the replicas drift apart
+    DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, visible_only ? vis_radii : nullptr, m.n));
     if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
         DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
                                         m.cfg.noiselr * lr_pos, (uint32_t)it));
@@ -776,7 +847,8 @@ float GaussianTrainerScene::getCurrentLoss() {
         const float w = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;
         double l1 = 0, ssim_sum = 0;
         for (int k = 0; k < DVS_SSIM_SLOTS; ++k) { l1 += h[k]; ssim_sum += h[DVS_SSIM_SLOTS + k]; }
-        m.last_loss = (float)l1 + (w > 0.f ? w * (1.f - (float)(ssim_sum / (3.0 * m.W * m.H))) : 0.f);
+        const double nv = (double)std::max(1, m.loss_views);             // the sums cover the step's views: report their mean
+        m.last_loss = (float)(l1 / nv) + (w > 0.f ? w * (1.f - (float)(ssim_sum / nv / (3.0 * m.W * m.H))) : 0.f);
     }
     return m.last_loss;
 }

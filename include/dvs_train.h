@@ -104,6 +104,13 @@ typedef struct dvs_densify_params {
 
 int dvs_densify_accumulate(void* stream, int n, const int32_t* radii, const float* absgrad2d, int width, int height,
                            float* grad_accum, float* denom, int32_t* max_radii);
+/* The same rule for every view of a multi-view pass (dvs_raster_forward_views), exactly as if the views had been accumulated one by
+ * one: radii [n_views][n] (dvs_fwd_state.radii of the batch), rows = the composite backward's intermediate rows [n_views][n][12]
+ * (dvs_get_bwd_intermediates) — call it between dvs_raster_backward_composite and dvs_raster_backward_project (which consumes them). */
+int dvs_densify_accumulate_rows(void* stream, int n, int n_views, const int32_t* radii, const float* rows, int width, int height,
+                                float* grad_accum, float* denom, int32_t* max_radii);
+/* out[i] = max over the views of radii[v][i] (> 0: visible in at least one view of the pass; the visible-only Adam step's gate) */
+int dvs_any_view_radius(void* stream, int n, int n_views, const int32_t* radii, int32_t* out);
 /* scratch: at least (n/256 + 2) uint32; new_count: DEVICE uint64. */
 int dvs_densify_plan(void* stream, int n, const float* opacity, const float* scale, const float* grad_accum, const float* denom,
                      const int32_t* max_radii, const dvs_densify_params* prm, uint8_t* action, uint32_t* offsets, uint32_t* scratch,

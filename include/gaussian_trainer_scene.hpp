@@ -53,6 +53,11 @@ struct GaussianTrainConfig {
     bool exportMesh = false, normalConsistencyLoss = false, useMask = false, verbose = true, bestQuality = false;
     bool enableBg = false, enableFocusRegion = false, cullSH = false, singleCamera = false, outputSparsePoints = false;
     bool visibleAdam = false, pixelGradScale = false;
+    // extension of this build (not a field of the reference's struct; appended last, default = the reference's behaviour): cameras
+    // rendered per trainStep() and GPU as ONE multi-view pass (BASELINE.json config C4: 8). Their gradients are summed — one
+    // optimizer step per trainStep, as after that many accumulated single-view steps. The environment variable DVS_VIEWS_PER_ITER
+    // overrides it (the reference's hosts do not know the field).
+    int viewsPerIter = 1;
 };
 
 class GaussianTrainerScene {

@@ -212,3 +212,37 @@ def test_cli_c5_shape(tmp_path):
     assert "Train Done" in p.stdout
     head = open(out + "_50.ply", "rb").read(400).decode(errors="ignore")
     assert f"element vertex {steps[-1][2]}" in head
+
+
+@pytest.mark.gpu
+def test_cli_eight_views_per_iteration_as_one_pass(tmp_path):
+    """BASELINE config C4 in the product: train_step renders 8 cameras per iteration as ONE multi-view pass (--viewsPerIter 8:
+    dvs_raster_forward_views / the split backward over all views), gradients summed, one optimizer step. Reference run: the same eight
+    cameras of every iteration one pass at a time with accumulating gradients (DVS_VIEWS_MODE=sequential). ADC refinement active in both
+    (per-view abs-grad statistics). The two must take the same refinement decisions and follow the same loss trajectory."""
+    def run(tag, env_extra):
+        out = str(tmp_path / tag / "iteration")
+        cmd = [DRIVER, "--inputPath", "synthetic:N=20000,W=320,H=240,cams=12,sh=2,seed=7", "--maxIteration", "500", "--outputPath", out,
+               "--viewsPerIter", "8", "--densifyStrategy", "0", "--warmupLength", "100", "--refineEvery", "100", "--refineStopIter", "350",
+               "--resetAlphaEvery", "3000", "--growGrad2d", "0.0004"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env_extra))
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        losses = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+)", p.stderr)]
+        dens = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"densify @(\d+): (\d+) -> (\d+) splats", p.stderr)]
+        return losses, dens, p.stderr
+    lb, db, errb = run("batch", {})
+    ls, ds, errs = run("seq", {"DVS_VIEWS_MODE": "sequential"})
+    assert "ONE multi-view pass" in errb and "one pass per view" in errs
+    assert len(lb) == len(ls) >= 5 and len(db) == len(ds) == 2, (lb, ls, db, ds)
+    assert lb[-1] < 0.6 * lb[0], lb                                   # it trains
+    for a, b in zip(lb[:3], ls[:3]):                                  # before the first refinement: the same trajectory to fp32 roundoff
+        assert abs(a - b) <= 2e-3 * abs(b), (lb, ls)
+    for a, b in zip(lb, ls):                                          # afterwards: the same level (refinement decisions sit on thresholds)
+        assert abs(a - b) <= 0.05 * abs(b), (lb, ls)
+    for (ia, na, ma), (ib, nb, mb) in zip(db, ds):                    # same schedule, counts within a per mille of each other
+        assert ia == ib and na > 0 and abs(ma - mb) <= max(4, 0.002 * mb), (db, ds)
+    # the environment override works for hosts that do not know the field
+    out = str(tmp_path / "env" / "iteration")
+    p = subprocess.run([DRIVER, "--inputPath", "synthetic:N=5000,W=160,H=96,cams=6,sh=1,seed=2", "--maxIteration", "20", "--outputPath", out],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, DVS_VIEWS_PER_ITER="4"))
+    assert p.returncode == 0 and "4 views per trainStep" in p.stderr, p.stderr[-1500:]
