@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--early-gather", type=int, default=1,
                     help="N>1, factorised exchange, --mode batch: 1 = the colour gradients are taken from the composite backward's rows "
                          "(dvs_raster_backward_dcolor) and their all-gather runs under the preprocess backward (A9)")
+    ap.add_argument("--a9-chunks", type=int, default=4,
+                    help="N>1, factorised exchange with the early gather: A9 runs in this many splat chunks and each chunk's 44 B/splat geometry "
+                         "all-reduce starts on the side stream as soon as its A9 launch is queued (SURVEY.md 8(e)); 1 = one all-reduce at the end")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture the step (one multi-view pass forward + loss gradient + backward) into a HIP graph after the warm-up and "
                          "replay it (one GPU, --mode batch, asynchronous forward: the pass has no host synchronisation and fixed launch shapes)")
@@ -281,6 +284,11 @@ def main():
         if not early:
             fx.set_combiner(lambda lo, hi, acc: rast.sh_grad_combine(params["pos"], campos_all[lo:hi], fx.dcolor_all[lo:hi], gbuf.views["sh0"],
                                                                      gbuf.views["shN"], deg, accumulate=acc, shn_tiled=tiled))
+    a9_chunks = None
+    if early and args.a9_chunks > 1 and tiled:
+        per = ((n + args.a9_chunks - 1) // args.a9_chunks + 255) // 256 * 256
+        a9_chunks = [(f, min(per, n - f)) for f in range(0, n, per)]
+    chunk_done = [torch.cuda.Event() for _ in (a9_chunks or [])]
     dcol_done = torch.cuda.Event()
     bwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
     fwd_done = [torch.cuda.Event() for _ in range(n_ctx)]
@@ -319,7 +327,13 @@ def main():
                     fx.gather_all(dcol_done)
                 if n_ctx > 1 and gi > 0:
                     st.wait_event(bwd_done[(gi - 1) % n_ctx])
-                rasts[c].backward_project(grads=g, accumulate=(gi > 0), factorised_sh=factorised)
+                if early and a9_chunks:           # A9 chunk by chunk, each chunk's geometry all-reduce leaving behind it on the side stream
+                    def _after(k_, first_, count_):
+                        chunk_done[k_].record(st)
+                        fx.reduce_geometry_chunk(gbuf, first_, count_, chunk_done[k_])
+                    rasts[c].backward_project_chunks(g, a9_chunks, _after, accumulate=(gi > 0))
+                else:
+                    rasts[c].backward_project(grads=g, accumulate=(gi > 0), factorised_sh=factorised)
                 if n_ctx > 1:
                     bwd_done[c].record(st)
                 if factorised and gi < K - 1:
@@ -606,7 +620,7 @@ def main():
                                    + (f" as {K} multi-view pass(es) of {G} view(s) (dvs_raster_forward_views / dvs_raster_backward_*)"
                                       + (" software-pipelined over two contexts/streams, gradients accumulated" if K > 1 else ""))
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "stagger": bool(args.stagger), "groups": K, "views_per_group": G, "early_gather": bool(early), "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "stagger": bool(args.stagger), "groups": K, "views_per_group": G, "early_gather": bool(early), "a9_chunks": len(a9_chunks) if a9_chunks else 1, "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,

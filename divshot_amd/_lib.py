@@ -81,6 +81,8 @@ _PROTOS = {
     "dvs_raster_backward_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Opts), C.c_void_p]),
     "dvs_raster_backward_project": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.c_void_p, C.POINTER(Opts),
                                               C.POINTER(SplatGrads)]),
+    "dvs_raster_backward_project_chunk": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.c_void_p, C.POINTER(Opts),
+                                                    C.POINTER(SplatGrads), C.c_int64, C.c_int64]),
     "dvs_raster_backward_dcolor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvs_sh_grad_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]),
@@ -111,6 +113,8 @@ _PROTOS = {
     "dvs_comm_reduce_scatter_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dvs_comm_all_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dvs_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "dvs_comm_group_start": (C.c_int, [C.c_void_p]),
+    "dvs_comm_group_end": (C.c_int, [C.c_void_p]),
     "dvs_last_error": (C.c_char_p, []),
     "dvs_version": (C.c_char_p, []),
     "dvs_synth_splats": (C.c_int, [C.POINTER(SceneSpec)] + [C.c_void_p] * 6),

@@ -86,6 +86,7 @@ struct dvs_ctx {
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
+    int64_t proj_next = 0;               // dvs_raster_backward_project_chunk: the next splat a chunk must start at
     int bwd_variant = DVS_BWD_TR;        // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create): the measured winner
     int fwd_variant = DVS_FWD_QUADRANT;  // which A7 kernel (dvs_set_forward_variant; env DVS_FWD_VARIANT at create)
     // stage timing: `timing` = every stage, synchronising per call (profiling iterations); `probe` = hipEvent pairs around the
@@ -411,6 +412,7 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, con
     if (c->probe) (void)probe_event(c, st);
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
+    c->proj_next = 0;
     return DVS_OK;
 }
 // A9: rows -> parameter gradients (re-zeroes the rows it reads). The tiled layout — one view or a batch — goes through ONE pass that
@@ -446,7 +448,8 @@ static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dv
         }
     }
     c->rows_clean = !c->keep_rows;        // every row render_bwd can have touched (radius > 0) was read and re-zeroed
-    c->rows_pending = false;
+    c->rows_pending = c->keep_rows;       // (kept rows can be projected again: the parity tests compare chunked and unchunked A9 on the same rows)
+    c->proj_next = 0;
     if (tm) { size_t e3 = tm->mark(); tm->span("preprocess_bwd", e2, e3); }
     return DVS_OK;
 }
@@ -515,6 +518,35 @@ int dvs_raster_backward_project(dvs_ctx* c, void* stream, const dvs_splats* p, c
     if (!c->rows_pending) { g_last_error = "dvs_raster_backward_project: no dvs_raster_backward_composite on this context"; return DVS_ERR_STATE; }
     HIPCHECK(hipSetDevice(c->device));
     return bwd_project(c, (hipStream_t)stream, p, cam, opts, out, nullptr);
+}
+
+int dvs_raster_backward_project_chunk(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
+                                      const dvs_splat_grads* out, int64_t first, int64_t count) {
+    int r;
+    if ((r = check_grads(p, out, "dvs_raster_backward_project_chunk")) != DVS_OK) return r;
+    if (!c) { g_last_error = "dvs_raster_backward_project_chunk: null argument"; return DVS_ERR_INVALID; }
+    if ((r = check_bwd_args(c, p, cam, c->n_views, opts, "dvs_raster_backward_project_chunk")) != DVS_OK) return r;
+    if (!c->rows_pending) { g_last_error = "dvs_raster_backward_project_chunk: no dvs_raster_backward_composite pending on this context"; return DVS_ERR_STATE; }
+    if (opts->shn_layout != DVS_SHN_TILED || !out->dcolor || out->sh0 || out->shN) {
+        g_last_error = "dvs_raster_backward_project_chunk: needs the DVS_SHN_TILED layout and the factorised form (out->dcolor given, sh0 / shN NULL)";
+        return DVS_ERR_INVALID;
+    }
+    if (first != c->proj_next || count <= 0 || first + count > p->n || (first % 256) != 0) {
+        g_last_error = "dvs_raster_backward_project_chunk: chunks must cover [0, n) in ascending order, each starting at a multiple of 256";
+        return DVS_ERR_INVALID;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    const dvs_fwd_state& s = c->st;
+    const int V = c->n_views, n = p->n;
+    DvsCams dcams;
+    for (int v = 0; v < V; ++v) dcams.c[v] = to_dev_cam(cam[v]);
+    HIPCHECK(dvs_launch_preprocess_bwd_views((hipStream_t)stream, n, V, p->pos, p->shN, p->opacity, p->scale, p->rot, dcams, opts->sh_degree,
+                                             opts->antialias, s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->opacity, out->scale,
+                                             out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor, opts->accumulate,
+                                             c->keep_rows ? 0 : 1, opts->grad_mode, (int)first, (int)count));
+    c->proj_next = first + count;
+    if (c->proj_next == n) { c->rows_clean = !c->keep_rows; c->rows_pending = c->keep_rows; c->proj_next = 0; }
+    return DVS_OK;
 }
 
 int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals, uint64_t n, int bit_lo, int bit_hi) {

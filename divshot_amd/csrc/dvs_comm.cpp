@@ -40,6 +40,8 @@ struct Rccl {
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     bool load(std::string& err) {
         if (handle) return true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -50,7 +52,7 @@ struct Rccl {
 #define SYM(field, name) field = (decltype(field))dlsym(handle, name); if (!field) { err = "librccl lacks " name; return false; }
         SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
         SYM(GetErrorString, "ncclGetErrorString") SYM(AllReduce, "ncclAllReduce") SYM(ReduceScatter, "ncclReduceScatter")
-        SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast")
+        SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
         return true;
     }
@@ -258,6 +260,16 @@ int dvs_comm_all_gather_f32(dvs_comm* c, void* stream, const float* send, float*
     if (!c || (send_count && (!send || !recv))) { dvs_set_last_error("dvs_comm_all_gather_f32: null argument"); return DVS_ERR_INVALID; }
     if (!send_count) return DVS_OK;
     RCCLCHECK(g_rccl.AllGather(send, recv, send_count, rcclFloat32, c->comm, (hipStream_t)stream));
+    return DVS_OK;
+}
+int dvs_comm_group_start(dvs_comm* c) {
+    if (!c) { dvs_set_last_error("dvs_comm_group_start: null communicator"); return DVS_ERR_INVALID; }
+    RCCLCHECK(g_rccl.GroupStart());
+    return DVS_OK;
+}
+int dvs_comm_group_end(dvs_comm* c) {
+    if (!c) { dvs_set_last_error("dvs_comm_group_end: null communicator"); return DVS_ERR_INVALID; }
+    RCCLCHECK(g_rccl.GroupEnd());
     return DVS_OK;
 }
 int dvs_comm_broadcast(dvs_comm* c, void* stream, void* buf, size_t bytes, int root) {

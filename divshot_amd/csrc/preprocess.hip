@@ -600,13 +600,14 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
                        float4* __restrict__ grad_rows /*[V,n,3]: A8 moments; re-zeroed here*/,
                        float* __restrict__ g_pos, float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
                        float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor /*[V,n,3]*/,
-                       int rezero, int grad_mode) {
+                       int rezero, int grad_mode, int i0 /*this launch covers the splats [i0, i1): all of them, or one chunk of a*/,
+                       int i1 /*data-parallel step that sends each chunk's gradients off while the next chunk computes*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*6]
     (void)cams_arg;
-    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int64_t base = (int64_t)i0 + (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
-    const bool valid = i < n;
-    const int il = valid ? i : (n - 1);
+    const bool valid = i < i1;
+    const int il = valid ? i : (i1 - 1);
     const float px = pos[3 * (int64_t)il], py = pos[3 * (int64_t)il + 1], pz = pos[3 * (int64_t)il + 2];
     const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
     const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
@@ -722,8 +723,8 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
 #pragma unroll
     for (int k = 0; k < 3; ++k) { l_pos[threadIdx.x * 3 + k] = gp[k]; l_scl[threadIdx.x * 3 + k] = gsc[k]; }
     __syncthreads();
-    stage_rows_out<3, ACCUM>(g_pos, l_pos, base, n);
-    stage_rows_out<3, ACCUM>(g_scale, l_scl, base, n);
+    stage_rows_out<3, ACCUM>(g_pos, l_pos, base, i1);
+    stage_rows_out<3, ACCUM>(g_scale, l_scl, base, i1);
 }
 
 // ---- factorised SH gradient: rows from per-view colour gradients -----------------------------------------------------
@@ -899,15 +900,17 @@ hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, c
                                            const float* scale, const float* rot, const DvsCams& cams, int deg, int antialias,
                                            const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos, float* g_opacity,
                                            float* g_scale, float* g_rot, float* out_absgrad2d, float* out_mean2d, float* out_dcolor,
-                                           int accumulate, int rezero, int grad_mode) {
+                                           int accumulate, int rezero, int grad_mode, int first, int count) {
     if (n <= 0 || n_views <= 0) return hipSuccess;
-    const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const int i0 = first < 0 ? 0 : first, i1 = count < 0 ? n : (first + count < n ? first + count : n);
+    if (i1 <= i0) return hipSuccess;
+    const int grid = (i1 - i0 + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = (size_t)PP_BLOCK * 6 * sizeof(float);
     static const bool nohoist = getenv("DVS_A9V_NOHOIST") && getenv("DVS_A9V_NOHOIST")[0] == '1';
 #define DVS_PPV1(A, N)                                                                                                          \
     hipLaunchKernelGGL((k_preprocess_bwd_views<A, N>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
                        deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_opacity, g_scale, g_rot,                         \
-                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero, grad_mode)
+                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero, grad_mode, i0, i1)
 #define DVS_PPV(A) do { if (nohoist) DVS_PPV1(A, true); else DVS_PPV1(A, false); } while (0)
     if (accumulate) DVS_PPV(true); else DVS_PPV(false);
 #undef DVS_PPV

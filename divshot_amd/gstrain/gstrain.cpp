@@ -97,6 +97,8 @@ struct GaussianTrainerScene::Impl {
     float* d_dcolor_local = nullptr; float* d_dcolor_all = nullptr;          // [cap,3] / [world,n,3]
     float* d_dcolor_scratch = nullptr;                                       // A9's own copy of the colour gradient (the all-gather reads the early one)
     hipStream_t comm_stream = nullptr; hipEvent_t ev_dcolor = nullptr, ev_bwd = nullptr, ev_comm = nullptr;   // collectives run beside A9
+    hipEvent_t ev_gather = nullptr; std::vector<hipEvent_t> ev_chunk;        // all-gather done / A9 chunk k queued (chunked geometry all-reduce)
+    int a9_chunks = 4;                                                       // DVS_A9_CHUNKS: splat chunks of A9 whose geometry gradients leave one by one
     std::vector<uint8_t*> d_targets_u8; float* d_target_f32 = nullptr;       // packLevel & PackF32ToU8
     std::vector<float*> d_masks;                                             // useMask
     std::vector<float> init_host[6];                                         // initial splats (resetGaussian, getPoints3D)
@@ -135,7 +137,9 @@ struct GaussianTrainerScene::Impl {
         d_masks.clear();
         for (float** p : {&d_grad_flat, &d_mean2d, &d_target_f32, &d_dcolor_local, &d_dcolor_all, &d_dcolor_scratch}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         if (d_vis_radius) { (void)hipFree(d_vis_radius); d_vis_radius = nullptr; }
-        for (hipEvent_t* e : {&ev_dcolor, &ev_bwd, &ev_comm}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        for (hipEvent_t* e : {&ev_dcolor, &ev_bwd, &ev_comm, &ev_gather}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
+        ev_chunk.clear();
         if (comm_stream) { (void)hipStreamDestroy(comm_stream); comm_stream = nullptr; }
         if (comm) { dvs_comm_destroy(comm); comm = nullptr; }
         for (void** p : {(void**)&d_grad_accum, (void**)&d_denom, (void**)&d_max_radii, (void**)&d_action, (void**)&d_offsets,
@@ -591,14 +595,18 @@ void GaussianTrainerScene::trainStep() {
         HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_scratch, (size_t)V * m.cap * 3 * sizeof(float) + 16));
         HIP_OR_THROW(hipMalloc((void**)&m.d_dcolor_all, (size_t)m.world * V * m.cap * 3 * sizeof(float) + 16));
         HIP_OR_THROW(hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&m.ev_dcolor, &m.ev_bwd, &m.ev_comm}) HIP_OR_THROW(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&m.ev_dcolor, &m.ev_bwd, &m.ev_comm, &m.ev_gather}) HIP_OR_THROW(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (const char* e = getenv("DVS_A9_CHUNKS")) m.a9_chunks = std::max(1, std::min(64, atoi(e)));
+        m.ev_chunk.resize((size_t)m.a9_chunks);
+        for (hipEvent_t& e : m.ev_chunk) HIP_OR_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    bool geom_reduced = false;                  // the geometry gradients already left chunk by chunk behind A9
     // densification statistics of the step's views, summed over the ranks in densify(): per view and visible
     // splat  grad_accum += |abs-grad|, denom += 1, max_radii = max
     const bool want_stats = refining && !mcmc;
     const int* vis_radii = nullptr;                                   // visible-only Adam: radius > 0 in any of the step's views
-    if (m.sequential_views || V == 1) {
-        // one pass per view (the reference's shape; with V > 1 the gradients accumulate over the views: DVS_VIEWS_MODE=sequential)
+    if (m.sequential_views) {
+        // one pass per view, gradients accumulating over the views (DVS_VIEWS_MODE=sequential: the reference shape, kept as the check of the multi-view pass)
         for (int v = 0; v < V; ++v) {
             opts.accumulate = v > 0 ? 1 : 0;
             DVS_OR_THROW(dvs_raster_forward(m.ctx, m.stream, &sp, &vcams[(size_t)v], &opts, m.d_out + (size_t)v * img, &m.fwd, nullptr));
@@ -628,7 +636,7 @@ void GaussianTrainerScene::trainStep() {
                 DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.fwd.radii, m.d_mean2d, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
             }
         }
-        vis_radii = m.fwd.radii;                // (V > 1 here: the last view's — visibleAdam is a single-view notion in this mode)
+        vis_radii = m.fwd.radii;                // (the last view's — visibleAdam is a single-view notion in this mode)
     } else {
         // ONE multi-view pass: parameters read once, one depth sort / scan / (view, tile) sort / composite launch for all V views, the
         // gradient rows written once (their sum over the views)
@@ -648,7 +656,28 @@ void GaussianTrainerScene::trainStep() {
             DVS_OR_THROW(dvs_get_bwd_intermediates(m.ctx, &rows, &rf));
             DVS_OR_THROW(dvs_densify_accumulate_rows(m.stream, m.n, V, m.fwd.radii, rows, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
         }
-        DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, vcams.data(), &opts, &g));
+        if (fact && m.a9_chunks > 1 && m.n >= 256 * m.a9_chunks) {
+            // A9 in splat chunks: as soon as chunk k is queued its 44 B/splat of geometry gradients (four ranges of the flat buffer, one
+            // grouped collective) start their all-reduce on the communication stream, under the A9 of the chunks behind it
+            HIP_OR_THROW(hipEventRecord(m.ev_gather, m.comm_stream));            // (behind the colour all-gather queued above)
+            const int per = ((m.n + m.a9_chunks - 1) / m.a9_chunks + 255) / 256 * 256;
+            int k = 0;
+            for (int first = 0; first < m.n; first += per, ++k) {
+                const int count = std::min(per, m.n - first);
+                DVS_OR_THROW(dvs_raster_backward_project_chunk(m.ctx, m.stream, &sp, vcams.data(), &opts, &g, first, count));
+                HIP_OR_THROW(hipEventRecord(m.ev_chunk[(size_t)k], m.stream));
+                HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_chunk[(size_t)k], 0));
+                DVS_OR_THROW(dvs_comm_group_start(m.comm));
+                DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad[P_POS] + 3 * (size_t)first, 3 * (size_t)count));
+                DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad[P_SCALE] + 3 * (size_t)first, 3 * (size_t)count));
+                DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad[P_ROT] + 4 * (size_t)first, 4 * (size_t)count));
+                DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad[P_OPA] + (size_t)first, (size_t)count));
+                DVS_OR_THROW(dvs_comm_group_end(m.comm));
+            }
+            geom_reduced = true;
+        } else {
+            DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, vcams.data(), &opts, &g));
+        }
         if (want_stats && !absgrad) {
             // without abs-grad the multi-view pass hands out the SUM over the views of dL/dmean2D: its norm is accumulated once per step
             // for splats visible in at least one view (for V = 1 the reference rule; documented difference for V > 1)
@@ -657,34 +686,19 @@ void GaussianTrainerScene::trainStep() {
             hipLaunchKernelGGL(k_norm2, dim3((unsigned)((m.n + 255) / 256)), dim3(256), 0, m.stream, m.d_mean2d, m.d_mean2d, m.n);
             DVS_OR_THROW(dvs_densify_accumulate(m.stream, m.n, m.d_vis_radius, m.d_mean2d, m.W, m.H, m.d_grad_accum, m.d_denom, m.d_max_radii));
         }
-        if (m.cfg.visibleAdam && m.world == 1) {
+        if (V == 1) {
+            vis_radii = m.fwd.radii;
+        } else if (m.cfg.visibleAdam && m.world == 1) {
             if (!m.d_vis_radius) HIP_OR_THROW(hipMalloc((void**)&m.d_vis_radius, (size_t)m.cap * sizeof(int) + 16));
             DVS_OR_THROW(dvs_any_view_radius(m.stream, m.n, V, m.fwd.radii, m.d_vis_radius));
             vis_radii = m.d_vis_radius;
         }
     }
-    if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule)
-        DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
-    // data parallel, over RCCL / xGMI: all-gather of the views' colour gradients + all-reduce of the geometry groups, then every
-    // replica rebuilds the summed SH rows from all views (factorised) — or ONE sum-all-reduce of all six groups (they share a buffer)
-    if (fact) {             // (both collectives on the communication stream, in the same order on every rank)
-        HIP_OR_THROW(hipEventRecord(m.ev_bwd, m.stream));
-        HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_bwd, 0));
-        DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad_flat, m.geom_floats));
-        HIP_OR_THROW(hipEventRecord(m.ev_comm, m.comm_stream));
-        HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_comm, 0));
-        std::vector<float> campos(ci_all.size() * 3);               // slot order of the all-gather: [rank][local view]
-        for (size_t q = 0; q < ci_all.size(); ++q) for (int k = 0; k < 3; ++k) campos[q * 3 + k] = m.cams[(size_t)ci_all[q]].campos[k];
-        DVS_OR_THROW(dvs_sh_grad_combine(m.ctx, m.stream, m.n, m.d_param[P_POS], deg, (int)ci_all.size(), campos.data(), m.d_dcolor_all,
-                                         m.d_grad[P_SH0], m.d_grad[P_SHN], 0, DVS_SHN_TILED));
-    } else if (m.comm) {
-        DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.stream, m.d_grad_flat, m.grad_floats));
-    }
     // Adam, per-group learning rates (names gs_train.cpp:52-57; position lr decays exponentially init -> final, scaled by the scene extent)
     const float t = std::min(1.0f, (float)m.step / (float)std::max(1, m.cfg.numIters));
     const float lr_pos = m.extent * std::exp((1.f - t) * std::log(m.cfg.poslrInit) + t * std::log(m.cfg.poslrFinal));
     const float lr[6] = {lr_pos, m.cfg.featurelr, m.cfg.featurelr / 20.f, m.cfg.opacitylr, m.cfg.scalinglr, m.cfg.rotationlr};
-    // one launch for the six groups; shN chunks above the active SH degree have g = m = v = 0 (Adam is the identity there)
+    // one launch per set of groups; shN chunks above the active SH degree have g = m = v = 0 (Adam is the identity there)
     static const int width[6] = {3, 3, 45, 1, 3, 4};
     dvs_adam_group ag[6];
     for (int k = 0; k < 6; ++k) {
@@ -694,7 +708,41 @@ void GaussianTrainerScene::trainStep() {
     }
     if (deg == 0) ag[P_SHN].count = 0;
     const bool visible_only = m.cfg.visibleAdam && m.world == 1 && vis_radii;       // per-rank visibility would let the replicas drift apart
-    DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, visible_only ? vis_radii : nullptr, m.n));
+    const int* adam_gate = visible_only ? vis_radii : nullptr;
+    bool sh_adam_done = false;
+    // data parallel, over RCCL / xGMI: all-gather of the views' colour gradients + all-reduce of the geometry groups, then every
+    // replica rebuilds the summed SH rows from all views (factorised) — or ONE sum-all-reduce of all six groups (they share a buffer)
+    if (fact) {             // (all collectives on the communication stream, in the same order on every rank)
+        if (!geom_reduced) {
+            HIP_OR_THROW(hipEventRecord(m.ev_gather, m.comm_stream));            // (behind the colour all-gather)
+            HIP_OR_THROW(hipEventRecord(m.ev_bwd, m.stream));
+            HIP_OR_THROW(hipStreamWaitEvent(m.comm_stream, m.ev_bwd, 0));
+            DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad_flat, m.geom_floats));
+        }
+        HIP_OR_THROW(hipEventRecord(m.ev_comm, m.comm_stream));
+        // The SH rows need only the colour all-gather: they are rebuilt and their Adam step (sh0 + shN: 192 of the 236 B per splat) runs
+        // WHILE the geometry all-reduce is still on the links; the geometry groups follow when it has landed.
+        HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_gather, 0));
+        std::vector<float> campos(ci_all.size() * 3);               // slot order of the all-gather: [rank][local view]
+        for (size_t q = 0; q < ci_all.size(); ++q) for (int k = 0; k < 3; ++k) campos[q * 3 + k] = m.cams[(size_t)ci_all[q]].campos[k];
+        DVS_OR_THROW(dvs_sh_grad_combine(m.ctx, m.stream, m.n, m.d_param[P_POS], deg, (int)ci_all.size(), campos.data(), m.d_dcolor_all,
+                                         m.d_grad[P_SH0], m.d_grad[P_SHN], 0, DVS_SHN_TILED));
+        dvs_adam_group sh_groups[2] = {ag[P_SH0], ag[P_SHN]};
+        DVS_OR_THROW(dvs_adam_step_groups(m.stream, sh_groups, 2, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
+        sh_adam_done = true;
+        HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_comm, 0));
+    } else if (m.comm) {
+        DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.stream, m.d_grad_flat, m.grad_floats));
+    }
+    if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule): a function of the replicated
+                       // parameters, added once (after the exchange) on every rank
+        DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
+    if (sh_adam_done) {
+        dvs_adam_group geo_groups[4] = {ag[P_POS], ag[P_OPA], ag[P_SCALE], ag[P_ROT]};
+        DVS_OR_THROW(dvs_adam_step_groups(m.stream, geo_groups, 4, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
+    } else {
+        DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
+    }
     if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
         DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
                                         m.cfg.noiselr * lr_pos, (uint32_t)it));

@@ -93,6 +93,29 @@ class FactorisedExchange:
         self._comm = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._combiner = None
         self._n_combined = 0
+        self._geom_reduced = False        # the geometry groups went out chunk by chunk (reduce_geometry_chunk): communicate() skips the big one
+
+    def reduce_geometry_chunk(self, gbuf, first, count, ready=None, group=None):
+        """"launch the reduce for splat-chunk k as soon as A9 has finished chunk k". Sum-all-reduce of the four
+        geometry groups' rows [first, first + count) — 44 B/splat, four contiguous ranges of the flat buffer — on the exchange's side stream behind `ready` (an event recorded after the chunk's A9
+        launch): it runs under the A9 of the following chunks, so only the last chunk's reduce stays exposed."""
+        import torch.distributed as dist
+        self._geom_reduced = True
+        if self.world == 1 and not (_force() and dist.is_initialized()):
+            return
+        parts = [gbuf.views[k][first:first + count] for k in ("pos", "scale", "rot", "opacity")]
+        def run():          # (four collectives per chunk: torch has no public grouped launch; libgstrain.so issues them as ONE ncclGroup)
+            for t in parts:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if self._comm is None:
+            run()
+        else:
+            if ready is not None:
+                self._comm.wait_event(ready)
+            else:
+                self._comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                run()
 
     def set_combiner(self, fn):
         """fn(slot_lo, slot_hi, accumulate): rebuild the SH rows of slots [slot_lo, slot_hi) (dvs_sh_grad_combine) — when set, the
@@ -176,8 +199,9 @@ class FactorisedExchange:
                     self.gather_view(v, None, group)
         self._gathered = [False] * self.views_per_rank
         self._n_combined = 0
-        if self.world > 1 or (_force() and dist.is_initialized()):
+        if not self._geom_reduced and (self.world > 1 or (_force() and dist.is_initialized())):
             dist.all_reduce(gbuf.flat_geom, op=dist.ReduceOp.SUM, group=group)
+        self._geom_reduced = False
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
 

@@ -271,6 +271,21 @@ class Rasterizer:
                   "dvs_raster_backward_project")
         return grads
 
+    def backward_project_chunks(self, grads, chunks, after_chunk, accumulate=False, want_mean2d=False):
+        """A9 in splat chunks (dvs_raster_backward_project_chunk; factorised form: grads["dcolor"] given, SH rows rebuilt later).
+        chunks: [(first, count)] covering [0, n) in order; after_chunk(k, first, count) runs right behind chunk k's launch on the
+        current stream — a data-parallel step records an event there and starts that chunk's gradient all-reduce on its side stream."""
+        grads, opts, g = self._grad_args(grads, accumulate, want_mean2d, True)
+        sp = self._splats(self._params, self._tiled)
+        cam_arg = self._cams if getattr(self, "_cams", None) is not None else C.byref(self._cam)
+        with torch.cuda.device(self.tdev):
+            for k, (first, count) in enumerate(chunks):
+                check(lib.dvs_raster_backward_project_chunk(self.ctx, _stream_ptr(), C.byref(sp), cam_arg, C.byref(opts), C.byref(g),
+                                                            int(first), int(count)), "dvs_raster_backward_project_chunk")
+                if after_chunk is not None:
+                    after_chunk(k, first, count)
+        return grads
+
     def sh_grad_combine(self, pos, campos, dcolor_all, g_sh0, g_shN, sh_degree, accumulate=False, shn_tiled=False):
         """g_sh0/g_shN (+)= sum over views of the SH rows implied by dcolor_all [V,n,3]; campos: [V,3] host floats."""
         campos = np.ascontiguousarray(campos, np.float32)

@@ -43,6 +43,10 @@ int dvs_comm_all_reduce_max_i32(dvs_comm* comm, void* stream, int32_t* buf, size
 int dvs_comm_reduce_scatter_sum_f32(dvs_comm* comm, void* stream, const float* send /*[world*recv_count]*/, float* recv, size_t recv_count);
 int dvs_comm_all_gather_f32(dvs_comm* comm, void* stream, const float* send, float* recv /*[world*send_count]*/, size_t send_count);
 int dvs_comm_broadcast(dvs_comm* comm, void* stream, void* buf, size_t bytes, int root);
+/* The collectives between a group_start and its group_end are issued as ONE launch (ncclGroupStart / ncclGroupEnd): the four ranges a
+ * splat chunk's geometry gradients occupy in the flat buffer leave as one operation instead of four small ones. */
+int dvs_comm_group_start(dvs_comm* comm);
+int dvs_comm_group_end(dvs_comm* comm);
 
 #ifdef __cplusplus
 }

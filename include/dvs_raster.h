@@ -184,6 +184,14 @@ int dvs_raster_backward_composite(dvs_ctx* ctx, void* stream, const dvs_camera* 
 int dvs_raster_backward_project(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                                 const dvs_opts* opts, const dvs_splat_grads* out);
 
+/* dvs_raster_backward_project in CHUNKS of splats, for a data-parallel step that overlaps its gradient exchange with A9 (SURVEY.md
+ * §8(e): "launch the reduce for splat-chunk k as soon as A9 has finished chunk k"): each call turns the rows of the splats
+ * [first, first + count) into gradients; the chunks must cover [0, n) in ascending order, every `first` a multiple of 256; after the
+ * last one the pending rows are consumed as after dvs_raster_backward_project. Factorised form only (DVS_SHN_TILED, out->dcolor given,
+ * out->sh0 / out->shN NULL: the SH rows follow from dvs_sh_grad_combine). Results are bit-identical to the unchunked call. */
+int dvs_raster_backward_project_chunk(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
+                                      const dvs_opts* opts, const dvs_splat_grads* out, int64_t first, int64_t count);
+
 /* Between dvs_raster_backward_composite and dvs_raster_backward_project: dcolor [n_views,n,3] (DEVICE, 16-byte aligned) receives
  * the per-view colour gradients — the values dvs_raster_backward_project later writes to out->dcolor, bit for bit — so that a
  * data-parallel trainer can start their all-gather while A9 runs. Does not consume the pending rows. */

@@ -739,3 +739,64 @@ def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     with pytest.raises(dv.DvsError, match="max_views"):
         single.forward_views(Pd, cams, sh_degree=3, shn_tiled=tiled)
     single.close(); batch.close()
+
+
+def test_project_chunks_equal_project(gpu_device):
+    """dvs_raster_backward_project_chunk (A9 in splat chunks, so that a data-parallel step can send each chunk's geometry gradients off
+    while the next chunk computes): bit-identical to the unchunked call — single view and a 3-view pass, with and without accumulate —
+    and the state errors of the chunk API."""
+    import torch
+    from divshot_amd import DvsError
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H, V = 5003, 208, 120, 3
+    spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=4, seed=11)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, i) for i in range(V)]
+    tg = [torch.from_numpy(dv.synth_target(spec, i)).cuda() for i in range(V)]
+    r1 = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    rv = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+    Pd = params_to_device(P, r1.tdev)
+    Pd = dict(Pd); Pd["shN"] = r1.shn_relayout(Pd["shN"], n, to_tiled=True)
+    chunks = [(0, 1536), (1536, 2048), (3584, n - 3584)]
+    keys = ("pos", "scale", "rot", "opacity", "dcolor", "absgrad2d", "mean2d")
+
+    def both(r, fwd, dL, nv):
+        out = []
+        fwd()
+        r.keep_intermediates(True)        # the composite backward's rows stay, so that both forms of A9 read the SAME rows (two
+        r.backward_composite(dL)          # composite runs differ by the roundoff of their fp32 atomics)
+        for chunked in (False, True):
+            for acc in (False, True):
+                g = {k: torch.full_like(v, 0.25) for k, v in Pd.items()}
+                g["dcolor"] = torch.zeros((nv, n, 3), device=r.tdev) if nv > 1 else torch.zeros((n, 3), device=r.tdev)
+                g["absgrad2d"] = torch.full((n, 2), 0.5, device=r.tdev); g["mean2d"] = torch.full((n, 2), 0.5, device=r.tdev)
+                if chunked:
+                    seen = []
+                    r.backward_project_chunks(g, chunks, lambda k, f, c: seen.append((k, f, c)), accumulate=acc, want_mean2d=True)
+                    assert seen == [(k, f, c) for k, (f, c) in enumerate(chunks)]
+                else:
+                    r.backward_project(grads=g, accumulate=acc, want_mean2d=True, factorised_sh=True)
+                torch.cuda.synchronize()
+                out.append({k: g[k].clone() for k in keys})
+        for k in keys:
+            assert torch.equal(out[0][k], out[2][k]), k          # overwrite: chunked == whole
+            assert torch.equal(out[1][k], out[3][k]), k          # accumulate: chunked == whole
+        assert not torch.equal(out[0]["pos"], out[1]["pos"])
+        r.keep_intermediates(False)
+
+    img = r1.forward(Pd, cams[0], sh_degree=3, absgrad=True, shn_tiled=True)
+    both(r1, lambda: r1.forward(Pd, cams[0], sh_degree=3, absgrad=True, shn_tiled=True), ((img - tg[0]) / (W * H)).contiguous(), 1)
+    imgs = rv.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True)
+    dLv = torch.stack([(imgs[v] - tg[v]) / (W * H) for v in range(V)]).contiguous()
+    both(rv, lambda: rv.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True), dLv, V)
+    # out of order / misaligned / without a pending composite
+    g = {k: torch.zeros_like(v) for k, v in Pd.items()}; g["dcolor"] = torch.zeros((n, 3), device=r1.tdev)
+    r1.forward(Pd, cams[0], sh_degree=3, absgrad=True, shn_tiled=True)
+    with pytest.raises(DvsError):
+        r1.backward_project_chunks(g, [(0, n)], None)       # no composite backward pending
+    r1.backward_composite(((img - tg[0]) / (W * H)).contiguous())
+    with pytest.raises(DvsError):
+        r1.backward_project_chunks(g, [(256, 512)], None)
+    with pytest.raises(DvsError):
+        r1.backward_project_chunks(g, [(0, 100), (100, n - 100)], None)       # the second chunk does not start on a multiple of 256
+    r1.close(); rv.close()
