@@ -162,9 +162,12 @@ def main():
     ap.add_argument("--early-gather", type=int, default=1,
                     help="N>1, factorised exchange, --mode batch: 1 = the colour gradients are taken from the composite backward's rows "
                          "(dvs_raster_backward_dcolor) and their all-gather runs under the preprocess backward (A9)")
-    ap.add_argument("--a9-chunks", type=int, default=4,
+    ap.add_argument("--a9-chunks", type=int, default=1,
                     help="N>1, factorised exchange with the early gather: A9 runs in this many splat chunks and each chunk's 44 B/splat geometry "
-                         "all-reduce starts on the side stream as soon as its A9 launch is queued (SURVEY.md 8(e)); 1 = one all-reduce at the end")
+                         "all-reduce starts on the side stream as soon as its A9 launch is queued (SURVEY.md 8(e)); 1 (default) = one all-reduce "
+                         "at the end. Measured on the one-view-per-rank step over a 1-rank RCCL communicator: every chunk costs this Python "
+                         "host 0.06-0.1 ms of launches (four collectives + an event each; 1.02 / 1.14 / 1.23 ms per step at 1 / 2 / 4 chunks) and "
+                         "the step turns host-bound — libgstrain.so issues a chunk as one ncclGroup from C++ (7 us per chunk) and defaults to 4")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture the step (one multi-view pass forward + loss gradient + backward) into a HIP graph after the warm-up and "
                          "replay it (one GPU, --mode batch, asynchronous forward: the pass has no host synchronisation and fixed launch shapes)")
@@ -395,12 +398,12 @@ def main():
     other_mode = None
     if graph is None and args.steps >= 10:
         gm["mode"] = 1 - args.grad_mode
-        for _ in range(3):
+        for _ in range(5):
             step()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        k_other = max(5, min(20, args.steps))
+        k_other = max(5, min(50, args.steps))
         t1 = time.perf_counter()
         for _ in range(k_other):
             step()

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-3 artefact set (GPU box): tools/profile_round.sh + the one-view-per-step shape + its exchange over a 1-rank RCCL communicator
+TAG=${1:-r03}
+cd "$(dirname "$0")/.."
+bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1
+tail -18 gpurun_out/${TAG}_profile_round.log | cut -c1-160
+bash tools/profile_single.sh $TAG > gpurun_out/${TAG}_profile_single.log 2>&1
+# the per-rank step of an 8-GPU run (one view per step) with every collective of the exchange executed by RCCL on a 1-rank communicator
+DVS_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 python bench.py --global-views 1 --no-cpu-baseline --profile-iters 0 --steps 200 --warmup 20 > gpurun_out/${TAG}_bench_1view_rccl_1rank.json 2> gpurun_out/${TAG}_bench_1view_rccl_1rank.err
+python - <<PY
+import json
+for f in ("${TAG}_bench.json", "${TAG}_single_bench.json", "${TAG}_bench_1view_rccl_1rank.json", "${TAG}_bench_c5.json", "${TAG}_bench_pipelined.json"):
+    try:
+        d = json.loads(open("gpurun_out/" + f).read().strip().splitlines()[-1])
+        print(f, "views/s", round(d["value"], 1), "ms/step", round(d["ms_per_step"], 3), "comm", d.get("t_comm_exposed_ms_per_step"), "other", d.get("other_grad_mode"))
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
