@@ -10,8 +10,9 @@
 // Reference anchors: key idea gsplat_viewz_cs.hlsl:250-253, sortable float gaussian_common.hlsl:115-120,
 // the viewer's own 8-bit-digit LSD sort renderer/gpu_sort.cpp:16-25,54-91 (32-bit keys, Vulkan; not reused).
 //
-// Wave64 idioms: in the scatter, digits are ranked with 8 ballots + mbcnt (a stable 64-wide multisplit) and per-wave digit
-// counters in LDS; the histogram pass, which needs no ranks, counts with native integer LDS atomics (ds_add_u32).
+// Wave64 idioms: in the sweep, digits are ranked with 8 ballots + mbcnt (a stable 64-wide multisplit) and per-wave digit counters in
+// LDS; the global histograms, which need no ranks, count with native integer LDS atomics (ds_add_u32).
+#include <cstdlib>
 #include "dvs_device.h"
 #include "dvs_kernels.h"
 
@@ -215,12 +216,7 @@ k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict_
 
 static inline int sort_items_for(uint64_t n) { return n <= 1500000ull ? 8 : 16; }
 
-size_t dvs_sort_scratch_words(uint64_t n) {
-    const uint64_t nb = (n + SORT_BLOCK * 8 - 1) / (SORT_BLOCK * 8);      // sized for the smaller partition
-    return (size_t)(nb * RADIX + RADIX);
-}
-
-hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+static hipError_t launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                                 uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch, const uint64_t* n_dev,
                                 uint64_t n_expected) {
     if (n == 0) return hipSuccess;
@@ -241,6 +237,261 @@ hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const u
     else
         hipLaunchKernelGGL(k_sort_scatter<16>, dim3(ng), dim3(SORT_BLOCK), 0, st, keys_in, vals_in, keys_out, vals_out, n, n_dev, shift,
                            dmask, hist, totals, nb);
+    return hipGetLastError();
+}
+
+// ---- A5, measured alternative (DVS_SORT_ONESWEEP=1): one "sweep" kernel per 8-bit pass with chained-scan partition prefixes ---------
+// The default above runs three kernels per pass (per-partition histogram, row scan, scatter: the keys are read twice per pass, 18
+// launches per forward). SURVEY.md §8 A5 names the alternative ("onesweep"), built here and measured SLOWER on this chip (C3, per
+// 8-view step 5.97 vs 5.77 ms; single view: depth sort 0.124 vs 0.079 ms, tile sort 0.102 vs 0.065 ms): with ~1000 workgroups resident,
+// all of them publish their counts at about the same time, so a partition looks back over hundreds of "count only" predecessors, one
+// dependent cross-XCD load (~1 us) per step and digit thread — the chain the reduce-then-scan form replaces by one 7-us row scan.
+// A wave-parallel look-back (64 predecessors per step from a [digit][partition] status layout) would cost about as many vector
+// instructions per partition as the ranking itself. Kept selectable, bit-exact like the default (tests/test_gpu_parity.py::test_sort_pairs).
+//   k_sort_ghist   ONE read of the keys per SORT: the global digit histograms of all its passes (they do not depend on the order
+//                  the earlier passes leave the keys in)
+//   k_sort_sweep   one launch per pass: a workgroup takes the next partition (a global ticket, so partitions start in order), ranks
+//                  its keys (stable wave64 multisplit, as before), publishes its per-digit counts in a status word, LOOKS BACK over
+//                  its predecessors' status words until it meets an inclusive prefix, publishes its own inclusive prefix, and
+//                  scatters — keys and values are read once and written once per pass.
+// A status word carries its value and its state in ONE 32-bit word (bits 31..30: 0 not ready / 1 this partition's count / 2 inclusive
+// prefix up to and including it), written and polled with relaxed agent-scope atomics: the per-XCD L2s are not coherent with each
+// other, but a single word written with an agent-scope store is seen whole by an agent-scope load on any XCD, and nothing else has to
+// be ordered against it (the scattered keys are read by the NEXT kernel). A partition only ever waits for partitions with smaller
+// tickets, whose workgroups already run: no deadlock by construction; a poll budget turns a broken chain into a reported error
+// (the instance-overflow counter: "outputs invalid") instead of a hang.
+#define OS_FLAG_AGG 1u
+#define OS_FLAG_INC 2u
+#define OS_VALUE_MASK 0x3FFFFFFFu
+#define OS_MAX_PASSES 4
+#define OS_POLL_BUDGET (1u << 22)
+
+__device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct OsPasses { int npass; int shift[OS_MAX_PASSES]; uint32_t dmask[OS_MAX_PASSES]; };
+
+// global digit histograms of all passes: ghist[pass][256]
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_ghist(const uint32_t* __restrict__ keys, uint64_t n_host, const uint64_t* __restrict__ n_dev, OsPasses ps, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[OS_MAX_PASSES][RADIX];
+    const uint64_t n = n_dev ? (*n_dev < n_host ? *n_dev : n_host) : n_host;
+    for (int e = threadIdx.x; e < OS_MAX_PASSES * RADIX; e += SORT_BLOCK) (&h[0][0])[e] = 0;
+    __syncthreads();
+    // 16 keys per thread and round: four 16-B loads in flight
+    const uint64_t per_round = (uint64_t)SORT_BLOCK * 16;
+    for (uint64_t base = (uint64_t)blockIdx.x * per_round; base < n; base += (uint64_t)gridDim.x * per_round) {
+        uint4 k4[4];
+        bool full[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t i0 = base + ((uint64_t)r * SORT_BLOCK + threadIdx.x) * 4;
+            full[r] = i0 + 4 <= n;
+            if (full[r]) k4[r] = reinterpret_cast<const uint4*>(keys)[i0 >> 2];
+            else {
+                k4[r].x = i0 < n ? keys[i0] : 0u; k4[r].y = i0 + 1 < n ? keys[i0 + 1] : 0u;
+                k4[r].z = i0 + 2 < n ? keys[i0 + 2] : 0u; k4[r].w = 0u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t i0 = base + ((uint64_t)r * SORT_BLOCK + threadIdx.x) * 4;
+            const uint32_t kk[4] = {k4[r].x, k4[r].y, k4[r].z, k4[r].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool valid = i0 + u < n;
+                for (int p = 0; p < ps.npass; ++p) {
+                    // the high bytes of a depth or tile key take few values: when the whole wave holds one digit, one lane adds the
+                    // count (64 same-address LDS atomics would serialise)
+                    const uint32_t d = (kk[u] >> ps.shift[p]) & ps.dmask[p];
+                    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                    const uint64_t vm = __ballot(valid);
+                    if (__ballot(valid && d != d0) == 0ull) {
+                        if (vm != 0ull && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(vm)) atomicAdd(&h[p][valid ? d : d0], (uint32_t)__popcll(vm));
+                    } else if (valid) {
+                        atomicAdd(&h[p][d], 1u);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ps.npass * RADIX; e += SORT_BLOCK) {
+        const uint32_t v = (&h[0][0])[e];
+        if (v) atomicAdd(&ghist[e], v);
+    }
+}
+
+template <int SORT_ITEMS>
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_sweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+             uint32_t* __restrict__ vals_out, uint64_t n_host, const uint64_t* __restrict__ n_dev, int shift, uint32_t dmask,
+             const uint32_t* __restrict__ ghist /*[256] of this pass*/, uint32_t* __restrict__ status /*[parts][256] of this pass, zeroed*/,
+             uint32_t* __restrict__ ticket /*zeroed*/, unsigned long long* __restrict__ err /*+1 when the look-back ran out of polls*/) {
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX];     // per-wave digit counts, then per-wave local bases
+    __shared__ uint32_t gdelta[RADIX];              // global destination of LDS slot s with digit d = gdelta[d] + s
+    __shared__ uint32_t gbase[RADIX];               // where digit d starts in the output (exclusive scan of the global histogram)
+    __shared__ uint32_t tmp[SORT_WAVES + 1];
+    __shared__ uint32_t s_part;
+    constexpr int SORT_PART = SORT_BLOCK * SORT_ITEMS;
+    __shared__ uint32_t stage_k[SORT_PART];
+    __shared__ uint32_t stage_v[SORT_PART];
+    const uint64_t n = n_dev ? (*n_dev < n_host ? *n_dev : n_host) : n_host;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    {
+        uint32_t tot;
+        gbase[threadIdx.x] = block_excl_scan(ghist[threadIdx.x], tmp, &tot);
+    }
+    for (;;) {
+        __syncthreads();                                 // (previous partition fully written; gbase visible)
+        if (threadIdx.x == 0) s_part = atomicAdd(ticket, 1u);
+        for (int e = threadIdx.x; e < SORT_WAVES * RADIX; e += SORT_BLOCK) (&cnt[0][0])[e] = 0;
+        __syncthreads();
+        const uint32_t part = s_part;
+        const uint64_t pbase = (uint64_t)part * SORT_PART;
+        if (pbase >= n) break;                           // (uniform per workgroup)
+        const uint64_t wbase = pbase + (uint64_t)wave * (64 * SORT_ITEMS);
+        uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            const bool valid = idx < n;
+            key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+            val[r] = valid ? vals_in[idx] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            const bool valid = idx < n;
+            const uint32_t d = (key[r] >> shift) & dmask;
+            const uint64_t peers = match_digit(d, valid);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            uint32_t prev = 0;
+            if (valid) {
+                prev = cnt[wave][d];                                   // in-order LDS: all peers read before the leader writes
+                if (below == 0) cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+            }
+            rank[r] = prev + below;
+        }
+        __syncthreads();
+        {
+            const uint32_t d = threadIdx.x;
+            uint32_t c[SORT_WAVES], bc = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) { c[w] = cnt[w][d]; bc += c[w]; }
+            // chained scan over the partitions, one digit per thread: publish this partition's count, look back, publish the prefix
+            uint32_t* const mine = status + (uint64_t)part * RADIX + d;
+            uint32_t excl = 0;
+            if (part == 0) {
+                os_store(mine, (OS_FLAG_INC << 30) | bc);
+            } else {
+                os_store(mine, (OS_FLAG_AGG << 30) | bc);
+                uint32_t polls = 0;
+                for (int64_t q = (int64_t)part - 1; q >= 0;) {
+                    const uint32_t sw = os_load(status + (uint64_t)q * RADIX + d);
+                    const uint32_t flag = sw >> 30;
+                    if (flag == 0u) {
+                        if (++polls > OS_POLL_BUDGET) { atomicAdd(err, 1ull); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += sw & OS_VALUE_MASK;
+                    if (flag == OS_FLAG_INC) break;
+                    --q;
+                }
+                os_store(mine, (OS_FLAG_INC << 30) | ((excl + bc) & OS_VALUE_MASK));
+            }
+            uint32_t tot;
+            const uint32_t loff = block_excl_scan(bc, tmp, &tot);                 // where digit d starts in the LDS stage
+            gdelta[d] = gbase[d] + excl - loff;
+            uint32_t run = loff;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) { cnt[w][d] = run; run += c[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint64_t idx = wbase + (uint64_t)r * 64 + lane;
+            if (idx < n) {
+                const uint32_t pos = cnt[wave][(key[r] >> shift) & dmask] + rank[r];
+                stage_k[pos] = key[r];
+                stage_v[pos] = val[r];
+            }
+        }
+        __syncthreads();
+        const uint32_t nvalid = (uint32_t)((n - pbase) < (uint64_t)SORT_PART ? (n - pbase) : (uint64_t)SORT_PART);
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const uint32_t slot = (uint32_t)i * SORT_BLOCK + threadIdx.x;
+            if (slot < nvalid) {
+                const uint32_t k = stage_k[slot];
+                const uint32_t dst = gdelta[(k >> shift) & dmask] + slot;
+                keys_out[dst] = k;
+                vals_out[dst] = stage_v[slot];
+            }
+        }
+    }
+}
+
+// scratch words of one sort of up to n items: [global histograms: 4 x 256][tickets: 64][status: 4 passes x partitions x 256]
+static inline uint64_t sort_parts(uint64_t n) { return (n + SORT_BLOCK * 8 - 1) / (SORT_BLOCK * 8); }      // sized for the smaller partition
+size_t dvs_sort_scratch_words(uint64_t n) { return (size_t)(OS_MAX_PASSES * RADIX + 64 + OS_MAX_PASSES * sort_parts(n) * RADIX); }   // (covers the default's nb * 256 + 256)
+
+// Stable LSD sort of (key, value) pairs over key bits [bit_lo, bit_hi): buffers 0 hold the input, the result is in buffers
+// (*result_in & 1). n sizes the scratch use and the grids; n_dev (nullable) is the device-side count, n_expected a grid hint for it.
+hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, uint64_t n, int bit_lo, int bit_hi,
+                           uint32_t* scratch, const uint64_t* n_dev, uint64_t n_expected, unsigned long long* err_counter, int* result_in) {
+    if (result_in) *result_in = 0;
+    if (n == 0 || bit_hi <= bit_lo) return hipSuccess;
+    static const bool onesweep = [] { const char* e = getenv("DVS_SORT_ONESWEEP"); return e && e[0] == '1'; }();
+    if (!onesweep) {                // default: histogram + row scan + scatter per pass
+        uint32_t* kk[2] = {keys0, keys1};
+        uint32_t* vv[2] = {vals0, vals1};
+        int c = 0;
+        for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+            hipError_t e = launch_sort_pass(st, kk[c], vv[c], kk[c ^ 1], vv[c ^ 1], n, shift, bit_hi - shift, scratch, n_dev, n_expected);
+            if (e != hipSuccess) return e;
+            c ^= 1;
+        }
+        if (result_in) *result_in = c;
+        return hipSuccess;
+    }
+    OsPasses ps{};
+    for (int shift = bit_lo; shift < bit_hi && ps.npass < OS_MAX_PASSES; shift += 8) {
+        const int bits = bit_hi - shift;
+        ps.shift[ps.npass] = shift; ps.dmask[ps.npass] = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
+        ++ps.npass;
+    }
+    const uint64_t n_grid = (n_dev && n_expected > 0 && n_expected < n) ? n_expected : n;
+    const int items = sort_items_for(n_grid);
+    const uint64_t part = (uint64_t)SORT_BLOCK * items;
+    const uint64_t nparts = (n + part - 1) / part;                               // status rows the kernels may touch (capacity)
+    uint32_t* ghist = scratch;
+    uint32_t* tickets = scratch + OS_MAX_PASSES * RADIX;
+    uint32_t* status = tickets + 64;
+    const size_t zero_words = (size_t)OS_MAX_PASSES * RADIX + 64 + (size_t)ps.npass * nparts * RADIX;
+    hipError_t e = hipMemsetAsync(scratch, 0, zero_words * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    uint64_t gparts = (n_grid + part - 1) / part;
+    uint32_t hgrid = (uint32_t)((n_grid + (uint64_t)SORT_BLOCK * 16 - 1) / ((uint64_t)SORT_BLOCK * 16));
+    if (hgrid > 512u) hgrid = 512u;
+    if (hgrid < 1u) hgrid = 1u;
+    hipLaunchKernelGGL(k_sort_ghist, dim3(hgrid), dim3(SORT_BLOCK), 0, st, keys0, n, n_dev, ps, ghist);
+    uint32_t sgrid = (uint32_t)(gparts + 1 < 4096 ? gparts + 1 : 4096);          // workgroups draw partitions until none are left
+    uint32_t* k[2] = {keys0, keys1};
+    uint32_t* v[2] = {vals0, vals1};
+    int cur = 0;
+    for (int p = 0; p < ps.npass; ++p) {
+        uint32_t* st_p = status + (size_t)p * nparts * RADIX;
+        if (items == 8)
+            hipLaunchKernelGGL(k_sort_sweep<8>, dim3(sgrid), dim3(SORT_BLOCK), 0, st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, n_dev, ps.shift[p],
+                               ps.dmask[p], ghist + p * RADIX, st_p, tickets + p, err_counter);
+        else
+            hipLaunchKernelGGL(k_sort_sweep<16>, dim3(sgrid), dim3(SORT_BLOCK), 0, st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, n_dev, ps.shift[p],
+                               ps.dmask[p], ghist + p * RADIX, st_p, tickets + p, err_counter);
+        cur ^= 1;
+    }
+    if (result_in) *result_in = cur;
     return hipGetLastError();
 }
 

@@ -250,11 +250,8 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
     // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
     int cur = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        HIPCHECK(dvs_launch_sort_pass(st, c->key[cur].as<uint32_t>(), c->ids[cur].as<uint32_t>(), c->key[cur ^ 1].as<uint32_t>(),
-                                      c->ids[cur ^ 1].as<uint32_t>(), (uint64_t)nV, pass * 8, 8, c->sort_scratch.as<uint32_t>()));
-        cur ^= 1;
-    }
+    HIPCHECK(dvs_launch_sort(st, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
+                             (uint64_t)nV, 0, 32, c->sort_scratch.as<uint32_t>(), nullptr, 0, (unsigned long long*)(c->total_dev + 1), &cur));
     size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
     // A3 scan in depth order (the one random gather of the binning stage: the tile rectangles)
     uint64_t T = 0, T_expected = 0;
@@ -301,12 +298,9 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     // A5 (high key bits): sort by (view, tile) over the instances
     int icur = 0;
     const int tile_bits = bits_for((uint32_t)(tiles * V - 1));
-    for (int shift = 0; shift < tile_bits; shift += 8) {
-        HIPCHECK(dvs_launch_sort_pass(st, c->inst_tile[icur].as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
-                                      c->inst_tile[icur ^ 1].as<uint32_t>(), c->inst_splat[icur ^ 1].as<uint32_t>(), T, shift,
-                                      tile_bits - shift, c->sort_scratch.as<uint32_t>(), T_dev, T_expected));
-        icur ^= 1;
-    }
+    HIPCHECK(dvs_launch_sort(st, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
+                             c->inst_splat[1].as<uint32_t>(), T, 0, tile_bits, c->sort_scratch.as<uint32_t>(), T_dev, T_expected,
+                             (unsigned long long*)(c->total_dev + 1), &icur));
     size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
     // A6 ranges
     HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles * V, T_dev, T_expected));
@@ -561,10 +555,8 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
     uint32_t* k[2] = {keys, c->tmp_keys.as<uint32_t>()};
     uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
     int cur = 0;
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        HIPCHECK(dvs_launch_sort_pass(st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, shift, bit_hi - shift, c->sort_scratch.as<uint32_t>()));
-        cur ^= 1;
-    }
+    HIPCHECK(dvs_launch_sort(st, k[0], v[0], k[1], v[1], n, bit_lo, bit_hi, c->sort_scratch.as<uint32_t>(), nullptr, 0,
+                             (unsigned long long*)(c->total_dev + 1), &cur));
     if (cur == 1) {
         HIPCHECK(hipMemcpyAsync(keys, k[1], n * 4, hipMemcpyDeviceToDevice, st));
         HIPCHECK(hipMemcpyAsync(vals, v[1], n * 4, hipMemcpyDeviceToDevice, st));

@@ -32,13 +32,14 @@ hipError_t dvs_launch_dcolor_from_rows(hipStream_t st, int64_t total, const int*
 hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, float* dst, int to_tiled);
 
 // binning.hip
-// Number of uint32 scratch words dvs_launch_sort_pass needs for n items.
+// Number of uint32 scratch words dvs_launch_sort needs for up to n items.
 size_t dvs_sort_scratch_words(uint64_t n);
-// One stable LSD pass (digit = `bits` (<= 8) key bits at `shift`) of (key,val) pairs: in -> out.
-// n_dev (nullable): the item count lives on the device (min(*n_dev, n) items are sorted; n sizes the grid) — no host round trip for T.
-hipError_t dvs_launch_sort_pass(hipStream_t st, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                                uint32_t* vals_out, uint64_t n, int shift, int bits, uint32_t* scratch, const uint64_t* n_dev = nullptr,
-                                uint64_t n_expected = 0 /*with n_dev: sizes the grid (the kernels stride over the partitions of n)*/);
+// Stable LSD radix sort (8-bit digits) of (key, value) pairs over key bits [bit_lo, bit_hi): one histogram kernel + one sweep kernel
+// per pass (chained-scan partition prefixes). Buffers 0 hold the input; *result_in = index (0 / 1) of the buffer pair with the result.
+// n_dev (nullable): the item count lives on the device (min(*n_dev, n) items are sorted; n bounds it) — no host round trip for T;
+// n_expected: grid hint for it. err_counter: device counter raised if the chained scan runs out of polls (outputs then invalid).
+hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, uint64_t n, int bit_lo, int bit_hi,
+                           uint32_t* scratch, const uint64_t* n_dev, uint64_t n_expected, unsigned long long* err_counter, int* result_in);
 // A3: gathers the tile rectangles (4 x u16 per splat, written by A2) into depth order, offsets over their areas. Writes block offsets
 // and total_dev[0] = T; total_dev[1] is incremented when T exceeds `capacity` (instances the arenas can hold).
 size_t dvs_scan_scratch_words(int n);

@@ -800,3 +800,15 @@ def test_project_chunks_equal_project(gpu_device):
     with pytest.raises(DvsError):
         r1.backward_project_chunks(g, [(0, 100), (100, n - 100)], None)       # the second chunk does not start on a multiple of 256
     r1.close(); rv.close()
+
+
+def test_sort_onesweep_variant_is_bit_exact_too(gpu_device):
+    """The chained-scan form of the radix sort (DVS_SORT_ONESWEEP=1: one sweep kernel per pass with look-back over the partitions'
+    status words; measured slower than the default on this chip, kept selectable) produces the same stable order: the sort test and two
+    pipeline configurations, bit-exact keys / values / ranges against the oracle, in a process that selects it."""
+    import subprocess, sys
+    env = dict(os.environ, DVS_SORT_ONESWEEP="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "test_sort_pairs or G2_2k_64_deg3 or C2_100k_800_deg3"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
