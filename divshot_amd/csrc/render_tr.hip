@@ -195,7 +195,8 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
 
     float T = T_final;
     float D = T_final * bg_dot;          // see k_render_bwd: one scalar of "colour behind" state suffices
-    float* const tbw = &s_tb[wave][lane];                                 // phase 1 writes (v5, w) of slot s at tbw[TR_SS s], tbw[TR_SS s + 64]
+    const uint32_t tb_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_tb[wave][0]);   // LDS byte offset of the wave's buffer (low half of the flat address), wave-uniform:
+                                                                          // phase 1 writes (v5, w) of slot s, lane l at floats [TR_SS s + l], [TR_SS s + 64 + l]
     const float* const tbr = &s_tb[wave][TR_SS * s2 + 16 * g2 + 4 * r2];  // phase 2 reads its row of four pixels: v5 at tbr[0..3], w at tbr[64..67]
     float* const tabw = &s_tab[wave][perm_r];
     const uint8_t* const lbase = &L.list[0];
@@ -275,7 +276,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         nmax = __builtin_amdgcn_readfirstlane(nmax);
         const int lastb = (int)min(last, (uint32_t)(base + BK)) - base;          // entries of this batch below the pixel's last contributor
         uint32_t p = (uint32_t)len * 16u + (uint32_t)blk1;                         // byte offset of the list's last element
-        uint32_t jn = lbase[p];
+        uint8_t jn = lbase[p];
         uint32_t jpack = 0;
         int nslot = 0;
 #pragma unroll 1
@@ -304,13 +305,16 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
             // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE: it passes as if alpha = opacity * G
             const bool gate = LINEAGE ? contrib : (contrib && !(oa > DVS_ALPHA_MAX));
             const float v5 = gate ? G * dL_dalpha : 0.f;
-            tbw[TR_SS * nslot] = v5;
-            tbw[TR_SS * nslot + 64] = w;
+            // the pair goes to slot nslot of the wave's buffer, lane-indexed: ds_write_addtid_b32 (address = M0 + offset + 4 lane) needs no
+            // address register and no vector instruction for the slot offset (the scalar unit moves the slot base into M0)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:256"
+                         : : "v"(v5), "v"(w), "s"(tb_m0 + (uint32_t)(TR_SS * 4) * (uint32_t)nslot) : "memory", "m0");
             jpack = (jpack << 8) | (uint32_t)j;
             if (++nslot == TR_SLOTS) { flush(jpack); nslot = 0; }
         }
         if (nslot > 0) {                                    // pad the unfinished round with the dummy entry (zero pairs, sink row)
             for (; nslot < TR_SLOTS; ++nslot) {
+                float* const tbw = &s_tb[wave][lane];
                 tbw[TR_SS * nslot] = 0.f; tbw[TR_SS * nslot + 64] = 0.f;
                 jpack = (jpack << 8) | (uint32_t)BK;
             }

@@ -39,7 +39,7 @@ def main():
         kernels[k] = {"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
                       "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
         if steps and ncalls.get(k, 0) >= steps:
-            kernels[k]["launches_per_step"] = ncalls[k] / steps
+            kernels[k]["launches_per_step"] = ncalls[k] // steps      # (the command's single extra forward adds a launch or two: dropped)
     how = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh) on bench.py's default workload, C3, "
            "1x MI355X. Units are KB (x1024). Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE "
            "reports half the bytes of wide coalesced reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibrated on "

@@ -11,7 +11,7 @@ python - <<PY
 import json
 for f in ("${TAG}_bench.json", "${TAG}_single_bench.json", "${TAG}_bench_1view_rccl_1rank.json", "${TAG}_bench_c5.json", "${TAG}_bench_pipelined.json"):
     try:
-        d = json.loads(open("gpurun_out/" + f).read().strip().splitlines()[-1])
+        d = json.loads([l for l in open("gpurun_out/" + f).read().splitlines() if l.startswith("{")][-1])
         print(f, "views/s", round(d["value"], 1), "ms/step", round(d["ms_per_step"], 3), "comm", d.get("t_comm_exposed_ms_per_step"), "other", d.get("other_grad_mode"))
     except Exception as e:
         print(f, "FAILED", e)
