@@ -1,5 +1,6 @@
-// render_blocks.hip — A7 / A8 with per-4x4-block splat lists. The A8 kernel here is the DEFAULT composite backward (since round 2);
-// the A7 kernel is a measured experiment (not faster than render.hip's, see the end of this header).
+// render_blocks.hip — A7 / A8 with per-4x4-block splat lists. The A8 kernel here was the default composite backward of round 2 (variant
+// "blocks"; round 3's default, render_tr.hip, keeps its lists and tables and replaces its per-step reduction); the A7 kernel is a
+// measured experiment (not faster than render.hip's, see the end of this header).
 //
 // The round-1 composite kernels walk, per 8x8 quadrant (= one wave), every splat whose alpha >= 1/255 ellipse reaches the quadrant;
 // on the bench scene a visit has 21 of 64 lanes contributing (a footprint of ~40 px inside the tile against a 64-px quadrant), and

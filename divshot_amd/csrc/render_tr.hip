@@ -19,7 +19,11 @@
 //            per-wave table (plain read-add-write, one block group at a time, as in render_blocks.hip).
 // Per list step: 32 + 80 / 4 = 52 vector instructions instead of 81 (ISA count, abs-grad on). The cursor is one saturating subtract:
 // the sixteen lists are stored interleaved behind a row of sentinels that point at an all-zero dummy entry (opacity 0 -> alpha 0 ->
-// "does not contribute"), so an exhausted group needs no predicate.
+// "does not contribute"), so an exhausted group needs no predicate. The pair is written with ds_write_addtid_b32 (LDS address = M0 +
+// offset + 4 lane: the scalar unit moves the slot base into M0). Measured: C3, 8-view launch 2.87-2.90 ms against 3.25-3.28 ms for the
+// round-2 kernel; SQ_INSTS_VALU -23 %, SQ_ACTIVE_INST_VALU -26 % (DESIGN.md section 5.1 with the ablations and the variants dropped
+// on the way: batches of 32, upstream gradients re-read per round, records prefetched in registers, conflict-free fast path, deferred
+// table steps — each stopped by the register count (78 of 80) or the LDS footprint (26.5 of 26.6 KB) at six workgroups per CU).
 //
 // Same inputs and the same 48-B row contract (moments about the mean, see dvs_get_bwd_intermediates) as the other A8 kernels; the
 // opacity factor of the moment / abs-grad sums is applied once per (tile, splat) when the tables are published.

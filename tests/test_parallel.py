@@ -95,6 +95,47 @@ def test_factorised_exchange_communication_gloo():
     assert abs(sums[0] - sums[1]) < 1e-3 * abs(sums[0])
 
 
+def _worker_chunks(rank, world, port, n, out):
+    sys.path.insert(0, ROOT)
+    from divshot_amd.parallel import GradBuffer, FactorisedExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gb = GradBuffer(n, torch.device("cpu"))
+    fx = FactorisedExchange(n, torch.device("cpu"), world, views_per_rank=1, rank_major=True)
+    fill = lambda r: (r + 1) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+    want = sum(range(1, world + 1)) * torch.arange(gb.flat_geom.numel(), dtype=torch.float32) * 1e-3
+    for step, chunks in enumerate(([(0, 256), (256, 256), (512, n - 512)], None, [(0, n)])):
+        gb.flat.zero_(); gb.flat_geom += fill(rank); gb.flat_sh.fill_(-1.0)
+        fx.dcolor_local[0].fill_(float(rank + step))
+        if chunks is not None:                               # the geometry rows go out chunk by chunk (A9 of chunk k+1 runs above chunk k's reduce)
+            for first, count in chunks:
+                fx.reduce_geometry_chunk(gb, first, count)
+        fx.communicate(gb)                                   # gathers dcolor; all-reduces the geometry slice only when no chunk went out
+        assert torch.allclose(gb.flat_geom, want, rtol=1e-6), (step, "geometry summed once, not twice")
+        assert bool((gb.flat_sh == -1.0).all())
+        for r in range(world):
+            assert bool((fx.dcolor_all[r] == float(r + step)).all())
+    out.put((rank, float(gb.flat_geom.sum())))
+    dist.destroy_process_group()
+
+
+def test_chunked_geometry_reduce_equals_one_reduce_gloo():
+    """SURVEY.md §8(e)'s chunked exchange on CPU: the four geometry groups reduced as three splat chunks (256-row boundaries, ragged
+    tail) sum to what one all-reduce of the slice gives, communicate() does not reduce them a second time, and the flag resets."""
+    world, n = 2, 700
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chunks, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sums = dict(out.get(timeout=5) for _ in range(world))
+    assert abs(sums[0] - sums[1]) < 1e-3 * abs(sums[0])
+
+
 def test_view_sharding():
     from divshot_amd.parallel import views_for_rank
     for world in (1, 2, 4, 8):
