@@ -28,7 +28,9 @@
 // Same inputs and the same 48-B row contract (moments about the mean, see dvs_get_bwd_intermediates) as the other A8 kernels; the
 // opacity factor of the moment / abs-grad sums is applied once per (tile, splat) when the tables are published.
 // Reference anchors as in render.hip (alpha rule gsplat_ps.hlsl:60-65, 16x16 groups gaussian_common.hlsl:162-163, abs-grad main.cpp:44).
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "dvs_device.h"
 #include "dvs_kernels.h"
 #include "render_common.h"
@@ -135,6 +137,9 @@ __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, 
     }
 }
 
+#ifdef TR_STATS
+__device__ unsigned long long tr_stats[8];
+#endif
 template <bool ABSGRAD, bool LINEAGE, int BK>
 __global__ void __launch_bounds__(RB, TR_MINW)
 k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
@@ -281,6 +286,21 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         nmax = max(nmax, __shfl_xor(nmax, 16, 64));
         nmax = max(nmax, __shfl_xor(nmax, 32, 64));
         nmax = __builtin_amdgcn_readfirstlane(nmax);
+#ifdef TR_STATS                                             // tools/xbuild.sh stats -DTR_STATS: step / imbalance counters of a launch on stderr
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0, wmx = 0, wsum = 0;
+            for (int w = 0; w < 4; ++w) {                   // wave w owns the blocks (2 (w & 1) + {0, 1}, 2 (w >> 1) + {0, 1})
+                uint32_t m = 0;
+                for (int g = 0; g < 4; ++g) { const uint32_t c = L.cnt[(2 * (w >> 1) + (g >> 1)) * 4 + 2 * (w & 1) + (g & 1)]; m = max(m, c); sum += c; }
+                wmx = max(wmx, m); wsum += m;
+            }
+            atomicAdd(&tr_stats[0], (unsigned long long)wsum);          // list steps summed over the waves
+            atomicAdd(&tr_stats[1], (unsigned long long)(4 * wmx));     // the same if every wave took as many as the batch's slowest (what the barrier costs)
+            atomicAdd(&tr_stats[2], (unsigned long long)sum);           // (block, entry) pairs
+            atomicAdd(&tr_stats[3], 1ull);                              // batches
+            atomicAdd(&tr_stats[4], (unsigned long long)cnt);           // staged entries
+        }
+#endif
         const int lastb = (int)min(last, (uint32_t)(base + BK)) - base;          // entries of this batch below the pixel's last contributor
         uint32_t p = (uint32_t)len * 16u + (uint32_t)blk1;                         // byte offset of the list's last element
         uint8_t jn = lbase[p];
@@ -365,6 +385,16 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
         else { if (lineage) DVS_TR(false, true, BKV); else DVS_TR(false, false, BKV); }                 \
     } while (0)
     DVS_TR_B(64);
+#ifdef TR_STATS
+    {
+        unsigned long long h[8];
+        hipStreamSynchronize(st);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(tr_stats), sizeof(h));
+        fprintf(stderr, "TR_STATS views %d: wave_steps %llu  if_lockstep %llu  block_pairs %llu  batches %llu  entries %llu\n", n_views, h[0], h[1], h[2], h[3], h[4]);
+        memset(h, 0, sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(tr_stats), h, sizeof(h));
+    }
+#endif
 #undef DVS_TR_B
 #undef DVS_TR
     return hipGetLastError();

@@ -1,9 +1,9 @@
 #!/bin/bash
-# same-box A/B of two builds of libdvsraster.so on the default bench step: tools/r3_ab.sh libA.so libB.so [rounds]
+# same-box A/B of builds of libdvsraster.so on the default bench step: ROUNDS=3 tools/r3_ab.sh libA.so libB.so ...
 cd "$(dirname "$0")/.."
-A=$1; B=$2; R=${3:-3}
+R=${ROUNDS:-3}
 for i in $(seq 1 $R); do
-for L in $A $B; do
+for L in "$@"; do
 DVS_RASTER_LIB=$PWD/$L timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-iters 3 2>/dev/null | python -c "
 import sys, json
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
