@@ -240,8 +240,18 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     // through LDS so that each store instruction covers 1 KB of consecutive addresses instead of 64 quarter lines.
     const float4 rc0 = make_float4(out_mean.x, out_mean.y, out_co.x, out_co.y);
     const float4 rc1 = make_float4(out_co.z, out_co.w, out_rgb[0], out_rgb[1]);
-    const float4 rc2 = make_float4(out_rgb[2], out_depth, __int_as_float(out_radius), 0.f);
-    const float4 rc3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // DVS_S2D_CULL: the constants of the composite kernels' ellipse-vs-rectangle tests (render.hip stage_batch), which depend on the
+    // splat alone — computed here once per splat and view instead of once per instance in A7 and four times per instance in A8
+    float cull_bound = 0.f, cull_det_c = 0.f, cull_det_a = 0.f, cull_nb_c = 0.f, cull_nb_a = 0.f;
+    if (out_radius > 0) {
+        const float a = out_co.x, b = out_co.y, c = out_co.z;
+        cull_bound = 1.3862943611f * __builtin_amdgcn_logf(255.0f * out_co.w) * 1.0001f + 1e-3f;      // 2 ln(255 o), inflated
+        const float det = fmaxf(0.f, __builtin_fmaf(-2.4e-7f, a * c, a * c - b * b));                  // lowered by its rounding bound
+        const float rc = __builtin_amdgcn_rcpf(c), ra = __builtin_amdgcn_rcpf(a);
+        cull_det_c = det * rc; cull_det_a = det * ra; cull_nb_c = -b * rc; cull_nb_a = -b * ra;
+    }
+    const float4 rc2 = make_float4(out_rgb[2], out_depth, __int_as_float(out_radius), cull_bound);
+    const float4 rc3 = make_float4(cull_det_c, cull_det_a, cull_nb_c, cull_nb_a);
     const int wave_base = (int)base + (int)(threadIdx.x & ~63u);
     if (wave_base + 64 <= n) {                 // (a whole wave of valid splats: uniform per wave)
         __shared__ float4 s_rec[PP_BLOCK * 4];

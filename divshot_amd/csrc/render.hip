@@ -43,9 +43,10 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
     uint32_t qm = 0;
     if (t < cnt) {
         const uint32_t id = sorted_splat[first + t];
-        // the splat's 64-B record (dvs_fwd_state.splat2d): three 16-B loads from ONE cache line
+        // the splat's 64-B record (dvs_fwd_state.splat2d): four 16-B loads from ONE cache line
         const float4 r0 = splat2d[4 * (size_t)id], r1 = splat2d[4 * (size_t)id + 1];
-        const float bl = splat2d[4 * (size_t)id + 2].x;
+        const float4 r2 = splat2d[4 * (size_t)id + 2], r3 = splat2d[4 * (size_t)id + 3];     // colour b | .. | DVS_S2D_CULL constants
+        const float bl = r2.x;
         const float2 xy = make_float2(r0.x, r0.y);
         const float4 co = make_float4(r0.z, r0.w, r1.x, r1.y);
         const float3 col = make_float3(r1.z, r1.w, bl);
@@ -60,11 +61,10 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         // y = clamp(y*, y0, y1)); every term is non-negative, so — unlike a x^2 + 2 b x y + c y^2 evaluated directly — nothing cancels
         // for thin, far-away splats, and det = a c - b^2 (which does cancel for them) is lowered by its own rounding bound: the
         // minimum is never over-estimated and the exact per-pixel test decides every contribution.
-        const float bound = 1.3862943611f * __builtin_amdgcn_logf(255.0f * co.w) * 1.0001f + 1e-3f;       // 2 ln 2 log2(255 o)
-        const float a = co.x, b = co.y, c = co.z;
-        const float det = fmaxf(0.f, __builtin_fmaf(-2.4e-7f, a * c, a * c - b * b));
-        const float rc = __builtin_amdgcn_rcpf(c), ra = __builtin_amdgcn_rcpf(a);
-        const float det_c = det * rc, det_a = det * ra, nb_c = -b * rc, nb_a = -b * ra;
+        // bound = 2 ln(255 o) inflated, det = a c - b^2 lowered by its rounding bound, det / c, det / a, -b / c, -b / a: per splat, from A2
+        const float bound = r2.w;
+        const float a = co.x, c = co.z;
+        const float det_c = r3.x, det_a = r3.y, nb_c = r3.z, nb_a = r3.w;
         const float ox = tile_x0 - xy.x, oy = tile_y0 - xy.y;                 // tile origin relative to the mean
         float vy[2], vbase[2], hx[2], hbase[2];
         bool vin[2], hin[2];

@@ -60,7 +60,7 @@ struct __attribute__((aligned(16))) TrLds {
 // The gather of a batch: splat ids (requested before the previous batch is published, so that round trip runs under the publish), then
 // the 64-B records. (Measured: requesting the records a batch ahead too and carrying them across the list loop costs more registers
 // than the kernel has at six waves per SIMD — the spills then serialise the loads.)
-struct TrRec { uint32_t id; float4 r0, r1; float bl; };
+struct TrRec { uint32_t id; float4 r0, r1, r2, r3; };      // r2 = colour b, depth, radius, cull bound; r3 = cull constants (DVS_S2D_CULL)
 template <int BK>
 __device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt) {
     const int e = threadIdx.x % BK;
@@ -69,9 +69,9 @@ __device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sort
 template <int BK>
 __device__ __forceinline__ TrRec tr_load_rec(const float4* __restrict__ splat2d, uint32_t id, int cnt) {
     TrRec R;
-    R.id = id; R.r0 = make_float4(0.f, 0.f, 0.f, 0.f); R.r1 = R.r0; R.bl = 0.f;
+    R.id = id; R.r0 = make_float4(0.f, 0.f, 0.f, 0.f); R.r1 = R.r0; R.r2 = R.r0; R.r3 = R.r0;
     if ((int)(threadIdx.x % BK) < cnt) {
-        R.r0 = splat2d[4 * (size_t)id]; R.r1 = splat2d[4 * (size_t)id + 1]; R.bl = splat2d[4 * (size_t)id + 2].x;
+        R.r0 = splat2d[4 * (size_t)id]; R.r1 = splat2d[4 * (size_t)id + 1]; R.r2 = splat2d[4 * (size_t)id + 2]; R.r3 = splat2d[4 * (size_t)id + 3];
     }
     return R;
 }
@@ -92,14 +92,11 @@ __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, 
         if (sub == 0) {
             L.ea[e] = make_float4(r0.x, r0.y, -0.72134752044448170f * a, -1.4426950408889634f * b);
             L.eb[e] = make_float4(-0.72134752044448170f * c, op, r1.z, r1.w);
-            L.ec[e] = make_float4(R.bl, a, b, c);
+            L.ec[e] = make_float4(R.r2.x, a, b, c);
             L.idop[parity][e] = make_uint2(R.id, __float_as_uint(op));
         }
         // exact ellipse-vs-block test from non-negative terms (derivation: render_blocks.hip stage_blocks / render.hip stage_batch)
-        const float bound = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op) * 1.0001f + 1e-3f;
-        const float det = fmaxf(0.f, __builtin_fmaf(-2.4e-7f, a * c, a * c - b * b));
-        const float rc = __builtin_amdgcn_rcpf(c), ra = __builtin_amdgcn_rcpf(a);
-        const float det_c = det * rc, det_a = det * ra, nb_c = -b * rc, nb_a = -b * ra;
+        const float bound = R.r2.w, det_c = R.r3.x, det_a = R.r3.y, nb_c = R.r3.z, nb_a = R.r3.w;      // per splat, from A2 (DVS_S2D_CULL)
         const float ox = tile_x0 - r0.x + 4.f * (float)col0, oy = tile_y0 - r0.y + 4.f * (float)row;
         const float y0 = oy, y1 = oy + 3.f;
         const bool hin = y0 <= 0.f && y1 >= 0.f;

@@ -114,13 +114,14 @@ enum { DVS_GRAD_TRUE = 0, DVS_GRAD_LINEAGE = 1 };
 /* Saved forward state. DEVICE pointers into ctx-owned arenas; valid until the next
  * dvs_raster_forward on the same ctx. Exposed so the parity tests can diff every stage. */
 enum { DVS_S2D_X = 0, DVS_S2D_Y = 1, DVS_S2D_CONIC = 2, DVS_S2D_OPACITY = 5, DVS_S2D_RGB = 6, DVS_S2D_DEPTH = 9, DVS_S2D_RADIUS = 10,
-       DVS_S2D_FLOATS = 16 };
+       DVS_S2D_CULL = 11, DVS_S2D_FLOATS = 16 };
 typedef struct dvs_fwd_state {
     /* per splat (n) */
     const int32_t*  radii;          /* 0 = culled */
     const float*    splat2d;        /* [n,16] the projected splat as ONE 64-byte record (one cache line per gather in A4/A7/A8):
                                        DVS_S2D_X, _Y pixel coords of the mean (pixel i centre = i) | _CONIC a,b,c | _OPACITY final opacity |
-                                       _RGB clamped colour r,g,b | _DEPTH view-space z | _RADIUS (int32 bits) | 5 unused floats */
+                                       _RGB clamped colour r,g,b | _DEPTH view-space z | _RADIUS (int32 bits) | _CULL five constants of the composite
+                                       kernels' conservative ellipse-vs-rectangle tests (internal: 2 ln(255 o) inflated, det/c, det/a, -b/c, -b/a) */
     const float*    depth;          /* [n] view-space z (also the sort key) */
     const uint32_t* flags;          /* [n] bit0..2 = SH clamp (colour channel <0), bit3 = fx clamped, bit4 = fy clamped */
     const uint32_t* tiles_touched;  /* [n] */
