@@ -72,6 +72,9 @@ struct dvs_ctx {
     int n_views = 1;                     // views of the last forward
     Buf radii, splat2d, depth, flags, tiles_touched, rect, rect_sorted, key[2], ids[2], scan_blocks;
     Buf inst_tile[2], inst_splat[2];
+    uint32_t* live_splat = nullptr;      // A7's compacted per-tile lists of the last forward (in the sort's spare instance arrays), or null
+    uint32_t* live_pos = nullptr;
+    bool live_lists = true;              // env DVS_LIVE_LISTS=0: A8 walks the full lists (A/B and parity of the two routes)
     Buf sort_scratch, tmp_keys, tmp_vals;
     Buf ranges, final_T, n_contrib;
     Buf g_rows;
@@ -192,6 +195,7 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
     if (const char* v = getenv("DVS_BWD_VARIANT"))
         c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_TR;
     if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
+    if (const char* v = getenv("DVS_LIVE_LISTS")) c->live_lists = v[0] != '0';
     if (hipMalloc((void**)&c->total_dev, 16) != hipSuccess || hipHostMalloc((void**)&c->total_host, 16, hipHostMallocDefault) != hipSuccess ||
         hipMemset(c->total_dev, 0, 16) != hipSuccess) {
         g_last_error = "dvs_create: hipMalloc failed";
@@ -307,10 +311,14 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     // A7 composite
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
-    if (c->fwd_variant == DVS_FWD_QUADRANT || V > 1)
+    // the live lists of A7 (entries that reach their tile, compacted) go into the sort's other pair of instance arrays, free by now
+    c->live_splat = nullptr; c->live_pos = nullptr;
+    if (c->fwd_variant == DVS_FWD_QUADRANT || V > 1) {
+        if (c->live_lists) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
         HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
-                                       c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
-    else
+                                       c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>(),
+                                       c->live_splat, c->live_pos));
+    } else
         HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                               c->splat2d.as<float>(), cam->bg, out_rgb,
                                               c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
@@ -395,7 +403,7 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, con
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(1); }
     if (c->bwd_variant == DVS_BWD_TR)
         HIPCHECK(dvs_launch_render_bwd_tr(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d, bgs, s.final_T,
-                                          s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
+                                          s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode, c->live_splat, c->live_pos));
     else if (c->bwd_variant == DVS_BWD_BLOCKS)
         HIPCHECK(dvs_launch_render_bwd_blocks(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d,
                                               bgs, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));

@@ -60,7 +60,9 @@ hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* so
 // render.hip — one launch covers the tiles of all n_views views of a batch (view-major ranges / pixel arrays; bgs = [n_views][3])
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
-                                 uint32_t* n_contrib);
+                                 uint32_t* n_contrib, uint32_t* live_splat /*[T] out (or null): per tile, the entries whose alpha >= 1/255 ellipse
+                                 reaches the tile, compacted in list order from ranges[tile].x*/, uint32_t* live_pos /*[T] out (or null): list
+                                 position -> number of such entries before it in its tile*/);
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad, int grad_mode,
@@ -76,7 +78,9 @@ enum { DVS_FWD_BLOCKS = 0 /*per-4x4-block lists (experiment)*/, DVS_FWD_QUADRANT
 // render_tr.hip
 hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                     const uint32_t* sorted_splat, const float* splat2d, const float* bgs /*[n_views][3]*/, const float* final_T,
-                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode);
+                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode,
+                                    const uint32_t* live_splat /*the forward's live lists (dvs_launch_render_fwd), or null: walk sorted_splat*/,
+                                    const uint32_t* live_pos);
 
 // render_blocks.hip
 hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,

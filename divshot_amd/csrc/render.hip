@@ -35,14 +35,18 @@ struct __attribute__((aligned(16))) BatchLds {
     float4 cog[RB];     // conic a, b, c as preprocess wrote them (gradient formulas), colour g
     float4 bl[RB];      // colour b in .x
     uint64_t qmask[RB / 64][4];
+    uint32_t wlive[RB / 64];    // A7: entries of the batch that reach the tile at all, per wave (see the live lists in k_render_fwd)
 };
 
-__device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt,
-                                            const float4* __restrict__ splat2d, float tile_x0, float tile_y0) {
+// Returns the lane's entry: its splat id in `id_out` and whether it reaches any quadrant of the tile.
+__device__ __forceinline__ bool stage_batch(BatchLds& L, const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt,
+                                            const float4* __restrict__ splat2d, float tile_x0, float tile_y0, uint32_t& id_out) {
     const int t = threadIdx.x;
     uint32_t qm = 0;
+    id_out = 0u;
     if (t < cnt) {
         const uint32_t id = sorted_splat[first + t];
+        id_out = id;
         // the splat's 64-B record (dvs_fwd_state.splat2d): four 16-B loads from ONE cache line
         const float4 r0 = splat2d[4 * (size_t)id], r1 = splat2d[4 * (size_t)id + 1];
         const float4 r2 = splat2d[4 * (size_t)id + 2], r3 = splat2d[4 * (size_t)id + 3];     // colour b | .. | DVS_S2D_CULL constants
@@ -91,6 +95,7 @@ __device__ __forceinline__ void stage_batch(BatchLds& L, const uint32_t* __restr
         uint64_t* dst = L.qmask[t >> 6];
         dst[0] = m0; dst[1] = m1; dst[2] = m2; dst[3] = m3;
     }
+    return qm != 0u;
 }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
@@ -103,7 +108,9 @@ __global__ void __launch_bounds__(RB)
 k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
              int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
-             float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib) {
+             float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
+             uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
+             uint32_t* __restrict__ live_pos /*[T] per list position: how many entries before it (in its tile) reach the tile*/) {
     __shared__ BatchLds L;
     (void)bg_arg;
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
@@ -123,12 +130,29 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
+    // Live lists for the composite backward: 28 % of a C3 tile list are entries whose alpha >= 1/255 ellipse misses the tile (the 3-sigma
+    // rectangle of A4 is wider). The staging test below already knows them; the entries that do reach the tile are written out compacted
+    // (same order), with the map list position -> live position, so that A8 stages, tabulates and publishes 28 % fewer entries.
+    uint32_t live_base = 0;
 
     for (int base = 0; base < total; base += RB) {
         if (__syncthreads_and(done)) break;
         const int cnt = min(RB, total - base);
-        stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
+        uint32_t my_id;
+        const bool live = stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE), my_id);
+        const uint64_t lm = __ballot(live);
+        const uint32_t lrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+        if (lane == 0) L.wlive[wave] = (uint32_t)__popcll(lm);
         __syncthreads();
+        if (live_pos) {
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < RB / 64; ++w) { const uint32_t c = L.wlive[w]; pre += w < wave ? c : 0u; tot += c; }
+            const uint32_t lp = live_base + pre + lrank;
+            if ((int)threadIdx.x < cnt) live_pos[range.x + base + threadIdx.x] = lp;
+            if (live) live_splat[range.x + lp] = my_id;
+            live_base += tot;
+        }
         if (__all(done)) continue;               // this wave's quadrant is finished
         // Predicated body (no per-lane branches: the scalar unit is shared by the CU's four SIMDs and a branchy
         // body made this kernel scalar-bound); the wave-uniform "everyone finished" exit is checked per 64-splat word.
@@ -231,7 +255,7 @@ k_render_bwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
         const int base = b * RB;
         const int cnt = min(RB, (int)todo - base);
         __syncthreads();
-        stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
+        { uint32_t id_unused; (void)stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE), id_unused); }
         __syncthreads();
 #pragma unroll 1
         for (int lw = RB / 64 - 1; lw >= 0; --lw) {
@@ -464,7 +488,7 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
         const int base = b * RB;
         const int cnt = min(RB, (int)todo - base);
         __syncthreads();
-        stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE));
+        { uint32_t id_unused; (void)stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE), id_unused); }
         __syncthreads();
 #pragma unroll 1
         for (int lw = RB / 64 - 1; lw >= 0; --lw) {
@@ -511,12 +535,12 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
-                                 uint32_t* n_contrib) {
+                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos) {
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib);
+                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos);
     return hipGetLastError();
 }
 

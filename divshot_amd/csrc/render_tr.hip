@@ -55,6 +55,9 @@ struct __attribute__((aligned(16))) TrLds {
     uint8_t list[(BK + 1) * 16];  // element k (1-based, list order) of block b at k * 16 + b; row 0 = sentinels (BK)
     uint32_t cnt[16];             // list lengths
     uint32_t blast[16];           // per block: deepest contributor of any of its pixels
+#ifdef TR_STATS
+    uint32_t live[BK];            // entry reaches at least one block
+#endif
 };
 
 // The gather of a batch: splat ids (requested before the previous batch is published, so that round trip runs under the publish), then
@@ -129,6 +132,9 @@ __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, 
             rk = up ? __builtin_amdgcn_mbcnt_hi(hi, 0u) : __builtin_amdgcn_mbcnt_lo(lo, 0u);
             len = (uint32_t)__popc(up ? hi : lo);
         }
+#ifdef TR_STATS
+        if (i == 0 && hits) atomicOr(&L.live[e], 1u);
+#endif
         if ((hits >> i) & 1u) L.list[(rk + 1u) * 16u + (uint32_t)(b0 + i)] = (uint8_t)e;
         if (e == 0) L.cnt[b0 + i] = len;
     }
@@ -143,7 +149,9 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
                 int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
                 const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
-                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg /*experiment knobs (timing only)*/) {
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg /*experiment knobs (timing only)*/,
+                const uint32_t* __restrict__ live_splat /*k_render_fwd's compacted lists (entries that reach the tile), or null*/,
+                const uint32_t* __restrict__ live_pos /*list position -> position in the compacted list*/) {
     __shared__ TrLds<BK> L;
     __shared__ float s_tab[4][(BK + 1) * 12];               // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
     __shared__ __attribute__((aligned(16))) float s_tb[4][TR_SLOTS * TR_SS];  // per wave: slot, plane (v5 | w), phase-1 lane
@@ -183,7 +191,11 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     const uint32_t jshift = 8u * (uint32_t)(TR_SLOTS - 1 - s2);
 
     const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    uint32_t last = inside ? n_contrib[pix] : 0u;
+    if (live_pos) {                                           // walk the forward's live list: same entries in the same order minus those that
+        if (last > 0u) last = live_pos[range.x + last - 1u] + 1u;     // cannot reach the tile; a contributor is always on it
+        sorted_splat = live_splat;
+    }
     float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f;
     if (inside) { dLp0 = dL_dout[pix]; dLp1 = dL_dout[P + pix]; dLp2 = dL_dout[2 * P + pix]; }
     const float bg_dot = (bgv.x * dLp0 + bgv.y * dLp1) + bgv.z * dLp2;
@@ -195,6 +207,9 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     if (pi == 0) L.blast[blk1] = bmax;
     for (int e = threadIdx.x; e < 4 * (BK + 1) * 12; e += RB) (&s_tab[0][0])[e] = 0.f;
     if (threadIdx.x < 16) L.list[threadIdx.x] = (uint8_t)BK;
+#ifdef TR_STATS
+    if (threadIdx.x < BK) L.live[threadIdx.x] = 0u;
+#endif
     if (threadIdx.x == 0) { L.ea[BK] = make_float4(0.f, 0.f, 0.f, 0.f); L.eb[BK] = make_float4(0.f, 0.f, 0.f, 0.f); L.ec[BK] = make_float4(0.f, 0.f, 0.f, 0.f); }
     __syncthreads();
     uint32_t todo = 0;
@@ -296,7 +311,12 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
             atomicAdd(&tr_stats[2], (unsigned long long)sum);           // (block, entry) pairs
             atomicAdd(&tr_stats[3], 1ull);                              // batches
             atomicAdd(&tr_stats[4], (unsigned long long)cnt);           // staged entries
+            uint32_t lv = 0;
+            for (int e2 = 0; e2 < cnt; ++e2) lv += L.live[e2];
+            atomicAdd(&tr_stats[5], (unsigned long long)lv);            // ... that reach at least one block of the tile
         }
+        __syncthreads();
+        if (threadIdx.x < BK) L.live[threadIdx.x] = 0u;
 #endif
         const int lastb = (int)min(last, (uint32_t)(base + BK)) - base;          // entries of this batch below the pixel's last contributor
         uint32_t p = (uint32_t)len * 16u + (uint32_t)blk1;                         // byte offset of the list's last element
@@ -366,7 +386,8 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
 // ---- launcher -------------------------------------------------------------------------------------------
 hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                     const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T,
-                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode) {
+                                    const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode,
+                                    const uint32_t* live_splat, const uint32_t* live_pos) {
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
@@ -375,7 +396,7 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
     const size_t extra_lds = dvs_experiment_extra_lds();
 #define DVS_TR(A, LN, BKV)                                                                                                          \
     hipLaunchKernelGGL((k_render_bwd_tr<A, LN, BKV>), dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, \
-                       num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, dbg)
+                       num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, dbg, live_splat, live_pos)
 #define DVS_TR_B(BKV)                                                                                   \
     do {                                                                                                \
         if (absgrad) { if (lineage) DVS_TR(true, true, BKV); else DVS_TR(true, false, BKV); }           \
@@ -387,7 +408,7 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
         unsigned long long h[8];
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(h, HIP_SYMBOL(tr_stats), sizeof(h));
-        fprintf(stderr, "TR_STATS views %d: wave_steps %llu  if_lockstep %llu  block_pairs %llu  batches %llu  entries %llu\n", n_views, h[0], h[1], h[2], h[3], h[4]);
+        fprintf(stderr, "TR_STATS views %d: wave_steps %llu  if_lockstep %llu  block_pairs %llu  batches %llu  entries %llu  live_entries %llu\n", n_views, h[0], h[1], h[2], h[3], h[4], h[5]);
         memset(h, 0, sizeof(h));
         hipMemcpyToSymbol(HIP_SYMBOL(tr_stats), h, sizeof(h));
     }
