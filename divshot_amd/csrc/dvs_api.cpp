@@ -634,6 +634,11 @@ int dvs_set_backward_variant(dvs_ctx* c, int variant) {
     c->bwd_variant = variant;
     return DVS_OK;
 }
+int dvs_set_live_lists(dvs_ctx* c, int enable) {
+    if (!c) { g_last_error = "dvs_set_live_lists: null context"; return DVS_ERR_INVALID; }
+    c->live_lists = enable != 0;
+    return DVS_OK;
+}
 int dvs_set_forward_variant(dvs_ctx* c, int variant) {
     if (!c || (variant != DVS_FWD_BLOCKS && variant != DVS_FWD_QUADRANT)) { g_last_error = "dvs_set_forward_variant: bad argument"; return DVS_ERR_INVALID; }
     c->fwd_variant = variant;

@@ -107,6 +107,10 @@ class Rasterizer:
         v = {"blocks": 0, "quadrant": 1}.get(variant, variant)
         check(lib.dvs_set_forward_variant(self.ctx, int(v)), "dvs_set_forward_variant")
 
+    def set_live_lists(self, on=True):
+        """dvs_set_live_lists: the forward's compacted per-tile lists for the "tr" backward (default on)."""
+        check(lib.dvs_set_live_lists(self.ctx, 1 if on else 0), "dvs_set_live_lists")
+
     def enable_timing(self, on=True):
         check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))
 

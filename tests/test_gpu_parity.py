@@ -741,6 +741,43 @@ def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     single.close(); batch.close()
 
 
+def test_live_lists_give_the_same_gradients(gpu_device):
+    """dvs_set_live_lists: the "tr" backward over the forward's compacted lists (entries that reach their tile) against the same
+    kernel over the full lists — one view and a 3-view pass, a scene with many entries that miss their tiles (small, faint splats) and
+    one with saturated stacks: equal to the roundoff of the fp32 atomics; the exported lists and n_contrib do not change."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    for (n, W, H, soff, seed) in ((6001, 200, 136, -0.5, 5), (3000, 96, 64, 1.2, 6)):
+        V = 3
+        spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=4, seed=seed, scale_log_offset=soff)
+        P = dv.synth_splats(spec)
+        cams = [dv.synth_camera(spec, i) for i in range(V)]
+        tg = torch.stack([torch.from_numpy(dv.synth_target(spec, i)) for i in range(V)]).cuda()
+        res = {}
+        for on in (False, True):
+            r = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+            r.set_backward_variant("tr"); r.set_live_lists(on)
+            Pd = params_to_device(P, r.tdev)
+            img1 = r.forward(Pd, cams[1], sh_degree=3, absgrad=True).clone()
+            s1 = r.saved()
+            g1 = {k: v.clone() for k, v in r.backward(((img1 - tg[1]) / (W * H)).contiguous()).items()}
+            Pt = dict(Pd); Pt["shN"] = r.shn_relayout(Pd["shN"], n, to_tiled=True)
+            imgs = r.forward_views(Pt, cams, sh_degree=3, absgrad=True, shn_tiled=True)
+            gv = {k: v.clone() for k, v in r.backward_views(((imgs - tg) / (W * H)).contiguous()).items()}
+            torch.cuda.synchronize()
+            res[on] = (img1, s1, g1, imgs.clone(), gv)
+            r.close()
+        a, b = res[False], res[True]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+        for k in ("vals", "sorted_tile", "ranges", "n_contrib"):
+            assert np.array_equal(a[1][k], b[1][k]), k
+        for ga, gb in ((a[2], b[2]), (a[4], b[4])):
+            for k in ("pos", "sh0", "shN", "opacity", "scale", "rot", "absgrad2d"):
+                if k in ga:
+                    x, y = ga[k].double(), gb[k].double()
+                    assert float((x - y).norm()) <= 2e-6 * float(x.norm()) + 1e-30, k
+
+
 def test_project_chunks_equal_project(gpu_device):
     """dvs_raster_backward_project_chunk (A9 in splat chunks, so that a data-parallel step can send each chunk's geometry gradients off
     while the next chunk computes): bit-identical to the unchunked call — single view and a 3-view pass, with and without accumulate —
