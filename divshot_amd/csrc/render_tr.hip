@@ -221,8 +221,14 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     float D = T_final * bg_dot;          // see k_render_bwd: one scalar of "colour behind" state suffices
     const uint32_t tb_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_tb[wave][0]);   // LDS byte offset of the wave's buffer (low half of the flat address), wave-uniform:
                                                                           // phase 1 writes (v5, w) of slot s, lane l at floats [TR_SS s + l], [TR_SS s + 64 + l]
-    const float* const tbr = &s_tb[wave][TR_SS * s2 + 16 * g2 + 4 * r2];  // phase 2 reads its row of four pixels: v5 at tbr[0..3], w at tbr[64..67]
-    float* const tabw = &s_tab[wave][perm_r];
+    // LDS byte addresses kept as opaque 32-bit values (the low half of a flat LDS address is the LDS offset): the compiler otherwise
+    // rebuilds them from two registers in every round
+    typedef __attribute__((address_space(3))) float lds_float;
+    typedef float tr_v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const tr_v4f lds_cv4f;
+    uint32_t tbr_a = (uint32_t)(uintptr_t)&s_tb[wave][TR_SS * s2 + 16 * g2 + 4 * r2];   // phase 2 reads its row of four pixels: v5 at floats 0..3, w at 64..67
+    uint32_t tabw_a = (uint32_t)(uintptr_t)&s_tab[wave][perm_r];
+    asm("" : "+v"(tbr_a), "+v"(tabw_a));
     const uint8_t* const lbase = &L.list[0];
 
     // phase 2: the wave's TR_SLOTS x 4 (slot, block) pairs, four lanes (pixel rows) per pair
@@ -230,10 +236,12 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         if (dbg & 4) return;
         const uint32_t jp = (uint32_t)__builtin_amdgcn_ds_bpermute(jaddr, (int)jpack);
         const int j = (int)((jp >> jshift) & 0xffu);
-        const float4 V = *reinterpret_cast<const float4*>(tbr);
-        const float4 Wv = *reinterpret_cast<const float4*>(tbr + 64);
+        const tr_v4f V_ = *(lds_cv4f*)tbr_a, W_ = *(lds_cv4f*)(tbr_a + 256u);
+        const float4 V = make_float4(V_.x, V_.y, V_.z, V_.w), Wv = make_float4(W_.x, W_.y, W_.z, W_.w);
         const float2 mean = *reinterpret_cast<const float2*>(&L.ea[j]);
         const float4 cq = L.ec[j];                                        // colour b | conic a, b, c
+        asm("" : : "v"(cq.x));                                            // (keeps the read ONE ds_read_b128: without a use of .x it is split into
+                                                                          //  two reads whose offsets need an extra address add)
         const float Dx = mean.x - X0f, Dy = mean.y - Y0f;                 // d = mean - pixel for the row's first pixel; pixel x: Dx - x
         const float A0 = (V.x + V.y) + (V.z + V.w);
         const float B0 = __builtin_fmaf(3.f, V.w, __builtin_fmaf(2.f, V.z, V.y));
@@ -272,7 +280,9 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         const float q0 = swap16_add(h0, h1), q1 = swap16_add(h2, h3), q2 = swap16_add(h4, h5);
         // one block group at a time: two groups may hold the same entry (measured: in nearly every round); LDS operations of one wave
         // execute in order, so a later group sees an earlier group's write
-        float* const slot = tabw + j * 12;
+        uint32_t slot_a;                                                  // = tabw_a + 48 j
+        asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(slot_a) : "v"(j), "v"(tabw_a));
+        lds_float* const slot = (lds_float*)slot_a;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g2 == g) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
@@ -320,22 +330,26 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
 #endif
         const int lastb = (int)min(last, (uint32_t)(base + BK)) - base;          // entries of this batch below the pixel's last contributor
         uint32_t p = (uint32_t)len * 16u + (uint32_t)blk1;                         // byte offset of the list's last element
-        uint8_t jn = lbase[p];
+        uint32_t jn = lbase[p];                                                    // (32 bits behind an opaque copy: the compiler narrows the loop
+        asm("" : "+v"(jn));                                                      //  variable to a byte otherwise and re-masks it every step)
         uint32_t jpack = 0;
         int nslot = 0;
 #pragma unroll 1
         for (int it = 0; it < ((dbg & 8) ? 0 : nmax); ++it) {
             const int j = (int)jn;
-            p = __builtin_elementwise_sub_sat(p, 16u);                             // an exhausted list parks on the sentinel row
-            jn = lbase[p];
+            jpack = (jpack << 8) | (uint32_t)j;                                    // (here: every use of j ahead of the next element's load)
+            const bool below_last = j < lastb;
             const float4 ea = L.ea[j];
             const float4 eb = L.eb[j];
+            p = __builtin_elementwise_sub_sat(p, 16u);                             // an exhausted list parks on the sentinel row
+            jn = lbase[p];
+            asm("" : "+v"(jn));
             const float dx = ea.x - pxf, dy = ea.y - pyf;
             const float p2 = __builtin_fmaf(eb.x * dy, dy, __builtin_fmaf(ea.w, dy, ea.z * dx) * dx);   // same expression as the forward
             const float G = __builtin_amdgcn_exp2f(p2);
             const float oa = eb.y * G;
             const float alpha = fminf(DVS_ALPHA_MAX, oa);
-            const bool contrib = (j < lastb) && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
+            const bool contrib = below_last && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
 #if TR_SKIP_EMPTY_STEPS
             if (__builtin_amdgcn_ballot_w64(contrib) == 0) continue;
 #endif
@@ -355,7 +369,6 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
             // address register and no vector instruction for the slot offset (the scalar unit moves the slot base into M0)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:256"
                          : : "v"(v5), "v"(w), "s"(tb_m0 + (uint32_t)(TR_SS * 4) * (uint32_t)nslot) : "memory", "m0");
-            jpack = (jpack << 8) | (uint32_t)j;
             if (++nslot == TR_SLOTS) { flush(jpack); nslot = 0; }
         }
         if (nslot > 0) {                                    // pad the unfinished round with the dummy entry (zero pairs, sink row)
