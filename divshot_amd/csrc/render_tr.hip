@@ -63,43 +63,34 @@ struct __attribute__((aligned(16))) TrLds {
 // The gather of a batch: splat ids (requested before the previous batch is published, so that round trip runs under the publish), then
 // the 64-B records. (Measured: requesting the records a batch ahead too and carrying them across the list loop costs more registers
 // than the kernel has at six waves per SIMD — the spills then serialise the loads.)
-struct TrRec { uint32_t id; float4 r0, r1, r2, r3; };      // r2 = colour b, depth, radius, cull bound; r3 = cull constants (DVS_S2D_CULL)
 template <int BK>
 __device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt) {
     const int e = threadIdx.x % BK;
     return e < cnt ? sorted_splat[first + e] : 0u;
 }
-template <int BK>
-__device__ __forceinline__ TrRec tr_load_rec(const float4* __restrict__ splat2d, uint32_t id, int cnt) {
-    TrRec R;
-    R.id = id; R.r0 = make_float4(0.f, 0.f, 0.f, 0.f); R.r1 = R.r0; R.r2 = R.r0; R.r3 = R.r0;
-    if ((int)(threadIdx.x % BK) < cnt) {
-        R.r0 = splat2d[4 * (size_t)id]; R.r1 = splat2d[4 * (size_t)id + 1]; R.r2 = splat2d[4 * (size_t)id + 2]; R.r3 = splat2d[4 * (size_t)id + 3];
-    }
-    return R;
-}
-
 // Stage the `cnt` entries of a batch (list positions base ..) and build the sixteen block lists. Thread t handles entry t % BK and the
 // GPT = 16 BK / 256 consecutive blocks starting at GPT * (t / BK) (one block row for BK = 64, half a row for BK = 32). All threads
 // holding one block sit in one wave (BK = 64) or one half wave (BK = 32), so ranks and lengths come straight from that wave's ballots.
 template <int BK>
-__device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, int base, int parity, float tile_x0, float tile_y0) {
+__device__ __forceinline__ void tr_stage(TrLds<BK>& L, const float4* __restrict__ splat2d, uint32_t id, int cnt, int base, int parity,
+                                         float tile_x0, float tile_y0) {
     constexpr int GPT = 16 * BK / RB;
     static_assert(GPT == 4 || GPT == 2, "BK must be 64 or 32");
     const int t = threadIdx.x, e = t % BK, sub = t / BK, lane = t & 63;
     const int b0 = GPT * sub, row = b0 >> 2, col0 = b0 & 3;
     uint32_t hits = 0;
     if (e < cnt) {
-        const float4 r0 = R.r0, r1 = R.r1;
+        // the 64-B record (dvs_fwd_state.splat2d): mean, conic | conic c, opacity, colour r g | colour b, -, -, cull bound | cull constants
+        const float4 r0 = splat2d[4 * (size_t)id], r1 = splat2d[4 * (size_t)id + 1], r2 = splat2d[4 * (size_t)id + 2], r3 = splat2d[4 * (size_t)id + 3];
         const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
         if (sub == 0) {
             L.ea[e] = make_float4(r0.x, r0.y, -0.72134752044448170f * a, -1.4426950408889634f * b);
             L.eb[e] = make_float4(-0.72134752044448170f * c, op, r1.z, r1.w);
-            L.ec[e] = make_float4(R.r2.x, a, b, c);
-            L.idop[parity][e] = make_uint2(R.id, __float_as_uint(op));
+            L.ec[e] = make_float4(r2.x, a, b, c);
+            L.idop[parity][e] = make_uint2(id, __float_as_uint(op));
         }
         // exact ellipse-vs-block test from non-negative terms (derivation: render_blocks.hip stage_blocks / render.hip stage_batch)
-        const float bound = R.r2.w, det_c = R.r3.x, det_a = R.r3.y, nb_c = R.r3.z, nb_a = R.r3.w;      // per splat, from A2 (DVS_S2D_CULL)
+        const float bound = r2.w, det_c = r3.x, det_a = r3.y, nb_c = r3.z, nb_a = r3.w;                // per splat, from A2 (DVS_S2D_CULL)
         const float ox = tile_x0 - r0.x + 4.f * (float)col0, oy = tile_y0 - r0.y + 4.f * (float)row;
         const float y0 = oy, y1 = oy + 3.f;
         const bool hin = y0 <= 0.f && y1 >= 0.f;
@@ -121,7 +112,8 @@ __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, 
     }
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
-        const uint64_t m = __ballot((hits >> i) & 1u);
+        const bool hit = (hits & (1u << i)) != 0u;
+        const uint64_t m = __ballot(hit);
         uint32_t rk, len;
         if (BK == 64) {
             rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -135,7 +127,7 @@ __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const TrRec& R, int cnt, 
 #ifdef TR_STATS
         if (i == 0 && hits) atomicOr(&L.live[e], 1u);
 #endif
-        if ((hits >> i) & 1u) L.list[(rk + 1u) * 16u + (uint32_t)(b0 + i)] = (uint8_t)e;
+        if (hit) L.list[(rk + 1u) * 16u + (uint32_t)(b0 + i)] = (uint8_t)e;
         if (e == 0) L.cnt[b0 + i] = len;
     }
 }
@@ -298,10 +290,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         const int base = b * BK;
         const int cnt = min(BK, (int)todo - base);
         // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
-        {
-            const TrRec R = tr_load_rec<BK>(splat2d, id_stage, cnt);
-            tr_stage<BK>(L, R, cnt, base, b & 1, tile_x0, tile_y0);
-        }
+        tr_stage<BK>(L, splat2d, id_stage, cnt, base, b & 1, tile_x0, tile_y0);
         __syncthreads();                                    // batch staged; the tables are zero again
         const int len = (int)L.cnt[blk1];
         int nmax = len;
