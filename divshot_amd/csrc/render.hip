@@ -35,11 +35,31 @@ struct __attribute__((aligned(16))) BatchLds {
     float4 cog[RB];     // conic a, b, c as preprocess wrote them (gradient formulas), colour g
     float4 bl[RB];      // colour b in .x
     uint64_t qmask[RB / 64][4];
-    uint32_t wlive[RB / 64];    // A7: entries of the batch that reach the tile at all, per wave (see the live lists in k_render_fwd)
 };
 
+// A7's own layout: everything a visit reads sits at ONE address in three arrays — two ds_read_b128 and one ds_read_b32.
+struct __attribute__((aligned(16))) FwdLds {
+    float4 a[RB];       // mean x, mean y, cs.x, cs.y
+    float4 b[RB];       // cs.z, opacity, colour r, colour g
+    float4 c[RB];       // colour b in .x (16-B stride as the other two: one address register serves the three reads)
+    uint64_t qmask[RB / 64][4];
+    uint32_t wlive[RB / 64];    // entries of the batch that reach the tile at all, per wave (see the live lists in k_render_fwd)
+};
+__device__ __forceinline__ void lds_put(BatchLds& L, int t, float2 xy, float4 co, float3 col, uint32_t id) {
+    L.xyc[t] = make_float4(xy.x, xy.y, -0.72134752044448170f * co.x, -1.4426950408889634f * co.y);
+    L.zoir[t] = make_float4(-0.72134752044448170f * co.z, co.w, __uint_as_float(id), col.x);
+    L.cog[t] = make_float4(co.x, co.y, co.z, col.y);
+    L.bl[t].x = col.z;
+}
+__device__ __forceinline__ void lds_put(FwdLds& L, int t, float2 xy, float4 co, float3 col, uint32_t) {
+    L.a[t] = make_float4(xy.x, xy.y, -0.72134752044448170f * co.x, -1.4426950408889634f * co.y);
+    L.b[t] = make_float4(-0.72134752044448170f * co.z, co.w, col.x, col.y);
+    L.c[t].x = col.z;
+}
+
 // Returns the lane's entry: its splat id in `id_out` and whether it reaches any quadrant of the tile.
-__device__ __forceinline__ bool stage_batch(BatchLds& L, const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt,
+template <class LDS>
+__device__ __forceinline__ bool stage_batch(LDS& L, const uint32_t* __restrict__ sorted_splat, uint32_t first, int cnt,
                                             const float4* __restrict__ splat2d, float tile_x0, float tile_y0, uint32_t& id_out) {
     const int t = threadIdx.x;
     uint32_t qm = 0;
@@ -54,10 +74,7 @@ __device__ __forceinline__ bool stage_batch(BatchLds& L, const uint32_t* __restr
         const float2 xy = make_float2(r0.x, r0.y);
         const float4 co = make_float4(r0.z, r0.w, r1.x, r1.y);
         const float3 col = make_float3(r1.z, r1.w, bl);
-        L.xyc[t] = make_float4(xy.x, xy.y, -0.72134752044448170f * co.x, -1.4426950408889634f * co.y);
-        L.zoir[t] = make_float4(-0.72134752044448170f * co.z, co.w, __uint_as_float(id), col.x);
-        L.cog[t] = make_float4(co.x, co.y, co.z, col.y);
-        L.bl[t].x = col.z;
+        lds_put(L, t, xy, co, col, id);
         // The splat can reach alpha >= 1/255 only where q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o), d = pixel - mean.
         // The minimum of the convex form over a quadrant's pixel rectangle is 0 if the mean lies inside, otherwise it lies on an edge
         // FACING the mean: the nearer vertical edge when the mean is left / right of the rectangle's columns, the nearer horizontal
@@ -111,7 +128,7 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
              float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
              uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
              uint32_t* __restrict__ live_pos /*[T] per list position: how many entries before it (in its tile) reach the tile*/) {
-    __shared__ BatchLds L;
+    __shared__ FwdLds L;
     (void)bg_arg;
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
     if (tile_g >= num_tiles) return;
@@ -127,7 +144,10 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile_g];
     const int total = (int)(range.y - range.x);
-    bool done = !inside;
+    // Pixel state that decides control flow lives in wave masks (scalar registers): `notdone` = pixels still compositing. A visit forms
+    // its predicates with three compares into masks, the scalar unit combines them, and the five updates of a contributing pixel
+    // (three colour FMAs, T, last contributor) run under EXEC = `take` — no v_cndmask per visit, no branch either.
+    uint64_t notdone = __builtin_amdgcn_ballot_w64(inside);
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
     // Live lists for the composite backward: 28 % of a C3 tile list are entries whose alpha >= 1/255 ellipse misses the tile (the 3-sigma
@@ -136,7 +156,7 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
     uint32_t live_base = 0;
 
     for (int base = 0; base < total; base += RB) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(notdone == 0ull)) break;
         const int cnt = min(RB, total - base);
         uint32_t my_id;
         const bool live = stage_batch(L, sorted_splat, range.x + base, cnt, splat2d, (float)(tx * DVS_TILE), (float)(ty * DVS_TILE), my_id);
@@ -153,35 +173,42 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
             if (live) live_splat[range.x + lp] = my_id;
             live_base += tot;
         }
-        if (__all(done)) continue;               // this wave's quadrant is finished
-        // Predicated body (no per-lane branches: the scalar unit is shared by the CU's four SIMDs and a branchy
-        // body made this kernel scalar-bound); the wave-uniform "everyone finished" exit is checked per 64-splat word.
+        if (notdone == 0ull) continue;           // this wave's quadrant is finished
+        // No per-lane branches (the scalar unit is shared by the CU's four SIMDs; a branchy body made this kernel scalar-bound); the
+        // wave-uniform "everyone finished" exit is checked per 64-splat word.
 #pragma unroll 1
         for (int lw = 0; lw < RB / 64; ++lw) {
             uint64_t m = uniform_u64(L.qmask[lw][wave]);
             if (m == 0) continue;
-            if (__all(done)) break;
+            if (notdone == 0ull) break;
             while (m) {
                 const int j = lw * 64 + __builtin_ctzll(m);
                 m &= m - 1;
-                const float4 xy = L.xyc[j];
-                const float4 zo = L.zoir[j];
-                const float4 cs = make_float4(xy.z, xy.w, zo.x, zo.y);
-                const float3 c = make_float3(zo.w, L.cog[j].w, L.bl[j].x);
-                const float dx = xy.x - pxf, dy = xy.y - pyf;
+                const float4 A = L.a[j];
+                const float4 B = L.b[j];
+                const float cb = L.c[j].x;
+                const float dx = A.x - pxf, dy = A.y - pyf;
                 // log2 of the Gaussian falloff: p2 = log2e * power (sign unchanged), one v_exp_f32, no extra multiply
-                const float p2 = __builtin_fmaf(cs.z * dy, dy, __builtin_fmaf(cs.y, dy, cs.x * dx) * dx);
-                const float alpha = fminf(DVS_ALPHA_MAX, cs.w * __builtin_amdgcn_exp2f(p2));
-                const bool valid = !done && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
+                const float p2 = __builtin_fmaf(B.x * dy, dy, __builtin_fmaf(A.w, dy, A.z * dx) * dx);
+                const float alpha = fminf(DVS_ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(p2));
                 const float aT = alpha * T;
                 const float test_T = T - aT;                       // = T (1 - alpha)
-                const bool stop = valid && (test_T < DVS_T_STOP);
-                const bool take = valid && !stop;
-                done = done || stop;
-                const float w = take ? aT : 0.f;
-                C0 = __builtin_fmaf(c.x, w, C0); C1 = __builtin_fmaf(c.y, w, C1); C2 = __builtin_fmaf(c.z, w, C2);
-                T = T - w;
-                last = take ? (uint32_t)(base + j + 1) : last;
+                const uint64_t m_ok = notdone & __builtin_amdgcn_ballot_w64(!(p2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < DVS_ALPHA_MIN));
+                const uint64_t m_lt = __builtin_amdgcn_ballot_w64(test_T < DVS_T_STOP);
+                const uint64_t m_take = m_ok & ~m_lt;              // contributes; (m_ok & m_lt: the pixel stops here, without this splat)
+                notdone &= ~(m_ok & m_lt);
+                const uint32_t idx = (uint32_t)(base + j + 1);
+                uint64_t saved_exec;
+                asm volatile("s_and_saveexec_b64 %[sv], %[tk]\n\t"
+                             "v_fmac_f32 %[c0], %[cr], %[at]\n\t"
+                             "v_fmac_f32 %[c1], %[cg], %[at]\n\t"
+                             "v_fmac_f32 %[c2], %[cbl], %[at]\n\t"
+                             "v_sub_f32 %[T], %[T], %[at]\n\t"
+                             "v_mov_b32 %[last], %[idx]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [c0] "+v"(C0), [c1] "+v"(C1), [c2] "+v"(C2), [T] "+v"(T), [last] "+v"(last), [sv] "=&s"(saved_exec)
+                             : [tk] "s"(m_take), [cr] "v"(B.z), [cg] "v"(B.w), [cbl] "v"(cb), [at] "v"(aT), [idx] "s"(idx)
+                             : "scc");                                  // (s_and_saveexec writes SCC)
             }
         }
     }
