@@ -181,12 +181,21 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
             uint64_t m = uniform_u64(L.qmask[lw][wave]);
             if (m == 0) continue;
             if (notdone == 0ull) break;
+            // LDS byte address of the word's first entry in a vector register (wave-uniform): a visit forms its address with ONE
+            // v_lshl_add from the scalar bit index instead of s_or + s_lshl + v_mov
+            typedef float fwd_v4f __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) const fwd_v4f lds_cv4f;
+            uint32_t word_a = (uint32_t)(uintptr_t)&L.a[lw * 64];
+            asm("" : "+v"(word_a));
+            const int idx0 = base + lw * 64 + 1;
             while (m) {
-                const int j = lw * 64 + __builtin_ctzll(m);
-                m &= m - 1;
-                const float4 A = L.a[j];
-                const float4 B = L.b[j];
-                const float cb = L.c[j].x;
+                const int bit = __builtin_ctzll(m);
+                asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));          // m &= m - 1 in one scalar instruction instead of three
+                uint32_t ent_a;
+                asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(ent_a) : "s"(bit), "v"(word_a));
+                const fwd_v4f A = *(lds_cv4f*)ent_a;
+                const fwd_v4f B = *(lds_cv4f*)(ent_a + (uint32_t)sizeof(L.a));
+                const float cb = *(const __attribute__((address_space(3))) float*)(ent_a + (uint32_t)(sizeof(L.a) + sizeof(L.b)));
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 // log2 of the Gaussian falloff: p2 = log2e * power (sign unchanged), one v_exp_f32, no extra multiply
                 const float p2 = __builtin_fmaf(B.x * dy, dy, __builtin_fmaf(A.w, dy, A.z * dx) * dx);
@@ -197,7 +206,7 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
                 const uint64_t m_lt = __builtin_amdgcn_ballot_w64(test_T < DVS_T_STOP);
                 const uint64_t m_take = m_ok & ~m_lt;              // contributes; (m_ok & m_lt: the pixel stops here, without this splat)
                 notdone &= ~(m_ok & m_lt);
-                const uint32_t idx = (uint32_t)(base + j + 1);
+                const uint32_t idx = (uint32_t)(idx0 + bit);
                 uint64_t saved_exec;
                 asm volatile("s_and_saveexec_b64 %[sv], %[tk]\n\t"
                              "v_fmac_f32 %[c0], %[cr], %[at]\n\t"
