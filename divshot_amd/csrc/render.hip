@@ -2,8 +2,10 @@
 //
 // One 16x16 tile per 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel quadrant so a
 // splat's footprint can be rejected per wave. The tile's depth-ordered splat list is streamed
-// through LDS in batches of 256 (one gathered splat per lane, then broadcast reads).
-// Backward replays the list back-to-front, reduces the 9 (11 with abs-grad) per-splat partials over
+// through LDS in batches of 256 (one gathered splat per lane, then broadcast reads). The forward (k_render_fwd) keeps the pixel predicates
+// in scalar wave masks and runs the updates of a contributing pixel under EXEC = take (21 vector + 12 scalar instructions per visit), and
+// writes per-tile live lists — the entries that reach the tile at all — for the default backward (render_tr.hip).
+// The backward in THIS file (variant "reduce", round 1) replays the list back-to-front, reduces the 9 (11 with abs-grad) per-splat partials over
 // the 64 lanes with v_permlane32/16_swap + ds_swizzle butterflies (LDS crossbar, no LDS memory) and publishes them with ONE
 // hardware fp32 atomic instruction per (wave, splat): 11 lanes add 11 consecutive floats of the splat's
 // 48-byte gradient row (global_atomic_add_f32; built with -munsafe-fp-atomics, no CAS loop).

@@ -20,7 +20,8 @@
 // Per list step: 32 + 80 / 4 = 52 vector instructions instead of 81 (ISA count, abs-grad on). The cursor is one saturating subtract:
 // the sixteen lists are stored interleaved behind a row of sentinels that point at an all-zero dummy entry (opacity 0 -> alpha 0 ->
 // "does not contribute"), so an exhausted group needs no predicate. The pair is written with ds_write_addtid_b32 (LDS address = M0 +
-// offset + 4 lane: the scalar unit moves the slot base into M0). Measured: C3, 8-view launch 2.87-2.90 ms against 3.25-3.28 ms for the
+// offset + 4 lane: the scalar unit moves the slot base into M0). The kernel walks the forward's live lists (k_render_fwd: the entries whose
+// alpha >= 1/255 ellipse reaches the tile, 72 % of a C3 list) when they exist: 2.48 ms. Measured before those: C3, 8-view launch 2.87-2.90 ms against 3.25-3.28 ms for the
 // round-2 kernel; SQ_INSTS_VALU -23 %, SQ_ACTIVE_INST_VALU -26 % (DESIGN.md section 5.1 with the ablations and the variants dropped
 // on the way: batches of 32, upstream gradients re-read per round, records prefetched in registers, conflict-free fast path, deferred
 // table steps — each stopped by the register count (78 of 80) or the LDS footprint (26.5 of 26.6 KB) at six workgroups per CU).
