@@ -15,6 +15,7 @@ value = 8 * K / time (whole job). `--views-per-step V` instead fixes V views per
 Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
+import datetime
 import json
 import math
 import os
@@ -131,6 +132,36 @@ def cpu_baseline(workload, max_seconds=60.0):
 cpu_baseline.reference = None
 
 
+def watchdog_seconds():
+    try:
+        return max(30.0, float(os.environ.get("DVS_BENCH_WATCHDOG_S", "900")))
+    except ValueError:
+        return 900.0
+
+
+def watchdog_record(args, message):
+    """The one JSON line of a run that did not finish: same keys as a result, value null, the reason in "error"."""
+    return {"metric": "train views/sec (fwd+bwd raster)", "value": None, "unit": "views/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": args.workload}, "error": message}
+
+
+def arm_rank_watchdog(args, rank):
+    """Inside a rank (also under an external launcher): a daemon timer that ends the process with an error line on rank 0 if the run has
+    not finished in time — a hung RCCL rendezvous or collective otherwise blocks in C++ where no Python exception can reach it."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            print(json.dumps(watchdog_record(args, f"rank 0 still running after {watchdog_seconds():.0f} s (hung collective or rendezvous?): aborted by bench.py's watchdog")), flush=True)
+        sys.stderr.write(f"[bench.py] rank {rank}: watchdog expired, exiting\n"); sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(watchdog_seconds() + (0.0 if rank == 0 else 10.0), fire)      # rank 0 first: its line is the one the caller reads
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +216,19 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd, env=env))
+        # watchdog: a rank stuck in a rendezvous or a collective must not hold the caller until ITS limit — after DVS_BENCH_WATCHDOG_S
+        # (default 900 s) the launcher's process group (started here, its own session) is killed and an error line is printed instead
+        child = subprocess.Popen(cmd, env=env, start_new_session=True)
+        try:
+            raise SystemExit(child.wait(timeout=watchdog_seconds() + 20.0))        # (the ranks' own watchdogs fire first and say more)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            print(json.dumps(watchdog_record(args, f"no result within {watchdog_seconds():.0f} s: the {args.gpus}-rank run was killed by bench.py's watchdog")), flush=True)
+            raise SystemExit(3)
 
     import numpy as np
     import torch
@@ -198,6 +241,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    watchdog = arm_rank_watchdog(args, rank) if world > 1 else None
+    if os.environ.get("DVS_BENCH_TEST_HANG") == "1" and world > 1:      # tests/test_parallel.py: a rank that never comes back
+        time.sleep(1e6)
     dist = None
     ndev = max(1, torch.cuda.device_count())
     if world > ndev and os.environ.get("DVS_DIST_BACKEND", "nccl") == "nccl":
@@ -212,9 +258,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         backend = os.environ.get("DVS_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=watchdog_seconds()))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=watchdog_seconds()))
 
     n, W, H, deg, soff = WORKLOADS[args.workload]
     weak = args.views_per_step > 0
@@ -685,6 +731,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

@@ -444,7 +444,9 @@ hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uin
     if (result_in) *result_in = 0;
     if (n == 0 || bit_hi <= bit_lo) return hipSuccess;
     static const bool onesweep = [] { const char* e = getenv("DVS_SORT_ONESWEEP"); return e && e[0] == '1'; }();
-    if (!onesweep) {                // default: histogram + row scan + scatter per pass
+    // The opt-in chained-scan form packs (flag, 30-bit prefix) into its status words: an inclusive prefix of 2^30 or more items in one
+    // digit bucket would spill into the flag bits, so sorts that large always take the default path.
+    if (!onesweep || n >= (1ull << 30)) {                // default: histogram + row scan + scatter per pass
         uint32_t* kk[2] = {keys0, keys1};
         uint32_t* vv[2] = {vals0, vals1};
         int c = 0;

@@ -84,6 +84,7 @@ struct dvs_ctx {
     uint64_t inst_cap = 0;               // instances the instance arenas can hold
     bool async_T = false;                // dvs_set_async: no host synchronisation inside dvs_raster_forward
     uint64_t overflow_seen = 0;          // value of total_host[1] already reported
+    uint64_t lookback_seen = 0;          // value of total_host[2] already reported (DVS_SORT_ONESWEEP only)
     dvs_fwd_state st{};
     bool have_fwd = false;
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
@@ -196,13 +197,13 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
         c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_TR;
     if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
     if (const char* v = getenv("DVS_LIVE_LISTS")) c->live_lists = v[0] != '0';
-    if (hipMalloc((void**)&c->total_dev, 16) != hipSuccess || hipHostMalloc((void**)&c->total_host, 16, hipHostMallocDefault) != hipSuccess ||
-        hipMemset(c->total_dev, 0, 16) != hipSuccess) {
+    if (hipMalloc((void**)&c->total_dev, 32) != hipSuccess || hipHostMalloc((void**)&c->total_host, 32, hipHostMallocDefault) != hipSuccess ||
+        hipMemset(c->total_dev, 0, 32) != hipSuccess) {
         g_last_error = "dvs_create: hipMalloc failed";
         delete c;
         return nullptr;
     }
-    c->total_host[0] = c->total_host[1] = 0;
+    c->total_host[0] = c->total_host[1] = c->total_host[2] = c->total_host[3] = 0;   // [0] T  [1] arena overflows  [2] broken look-back chains (chained-scan sort)
     if (const char* v = getenv("DVS_ASYNC")) c->async_T = v[0] == '1';
     if (ensure_splat_arenas(c, max_splats * (size_t)max_views) != DVS_OK || ensure_image_arenas(c, max_w, max_h, max_views) != DVS_OK ||
         ensure_instance_arenas(c, (uint64_t)max_splats * 4 * (uint64_t)max_views) != DVS_OK) {
@@ -255,7 +256,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
     int cur = 0;
     HIPCHECK(dvs_launch_sort(st, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
-                             (uint64_t)nV, 0, 32, c->sort_scratch.as<uint32_t>(), nullptr, 0, (unsigned long long*)(c->total_dev + 1), &cur));
+                             (uint64_t)nV, 0, 32, c->sort_scratch.as<uint32_t>(), nullptr, 0, (unsigned long long*)(c->total_dev + 2), &cur));
     size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
     // A3 scan in depth order (the one random gather of the binning stage: the tile rectangles)
     uint64_t T = 0, T_expected = 0;
@@ -265,6 +266,12 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         // forwards on this context (pinned copy, refreshed asynchronously): it grows the arenas ahead of need and reports an overflow
         // (T beyond the capacity: that view's outputs are invalid, nothing was written out of bounds) as DVS_ERR_CAPACITY, once.
         const uint64_t lastT = c->total_host[0], overflow = c->total_host[1];
+        if (c->total_host[2] != c->lookback_seen) {       // its own counter and message: growing the arena would not help
+            c->lookback_seen = c->total_host[2];
+            g_last_error = "dvs_raster_forward (async): the chained-scan sort (DVS_SORT_ONESWEEP=1) of an earlier forward ran out of look-back "
+                           "polls (preemption / profiler); that view's outputs are invalid — repeat it, or unset DVS_SORT_ONESWEEP.";
+            return DVS_ERR_STATE;
+        }
         if (overflow != c->overflow_seen) {
             c->overflow_seen = overflow;
             HIPCHECK(hipStreamSynchronize(st));
@@ -285,7 +292,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     }
     HIPCHECK(dvs_launch_tile_scan(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
                                   c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull));
-    HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 16, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 32, hipMemcpyDeviceToHost, st));
     size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
     if (!c->async_T) {
         HIPCHECK(hipStreamSynchronize(st));
@@ -304,7 +311,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     const int tile_bits = bits_for((uint32_t)(tiles * V - 1));
     HIPCHECK(dvs_launch_sort(st, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
                              c->inst_splat[1].as<uint32_t>(), T, 0, tile_bits, c->sort_scratch.as<uint32_t>(), T_dev, T_expected,
-                             (unsigned long long*)(c->total_dev + 1), &icur));
+                             (unsigned long long*)(c->total_dev + 2), &icur));
     size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
     // A6 ranges
     HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles * V, T_dev, T_expected));
@@ -314,7 +321,11 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     // the live lists of A7 (entries that reach their tile, compacted) go into the sort's other pair of instance arrays, free by now
     c->live_splat = nullptr; c->live_pos = nullptr;
     if (c->fwd_variant == DVS_FWD_QUADRANT || V > 1) {
-        if (c->live_lists) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
+        // Only the "tr" composite backward walks them (the other variants ignore them), and they cost the forward two 4-B stores per
+        // instance: none for an inference-only context (dvs_set_live_lists(ctx, 0)) or another backward. The spare pair of the tile
+        // sort's ping-pong buffers is RESERVED for them until the next forward on this context: nothing after the sort may reuse
+        // inst_*[icur ^ 1].
+        if (c->live_lists && c->bwd_variant == DVS_BWD_TR) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
         HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                        c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>(),
                                        c->live_splat, c->live_pos));
@@ -508,7 +519,11 @@ int dvs_raster_backward_composite(dvs_ctx* c, void* stream, const dvs_camera* ca
     if (!c) { g_last_error = "dvs_raster_backward_composite: null argument"; return DVS_ERR_INVALID; }
     if ((r = check_bwd_args(c, nullptr, cam, c->n_views, opts, "dvs_raster_backward_composite")) != DVS_OK) return r;
     HIPCHECK(hipSetDevice(c->device));
-    return bwd_composite(c, (hipStream_t)stream, cam, opts, dL_drgb, nullptr);
+    timing_reset(c);
+    StageTimer tm(c, (hipStream_t)stream);
+    if ((r = bwd_composite(c, (hipStream_t)stream, cam, opts, dL_drgb, &tm)) != DVS_OK) return r;
+    if (c->timing) { HIPCHECK(hipStreamSynchronize((hipStream_t)stream)); timing_collect(c, true); }
+    return DVS_OK;
 }
 
 int dvs_raster_backward_project(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
@@ -518,8 +533,16 @@ int dvs_raster_backward_project(dvs_ctx* c, void* stream, const dvs_splats* p, c
     if (!c) { g_last_error = "dvs_raster_backward_project: null argument"; return DVS_ERR_INVALID; }
     if ((r = check_bwd_args(c, p, cam, c->n_views, opts, "dvs_raster_backward_project")) != DVS_OK) return r;
     if (!c->rows_pending) { g_last_error = "dvs_raster_backward_project: no dvs_raster_backward_composite on this context"; return DVS_ERR_STATE; }
+    if (c->proj_next != 0) {       // earlier chunks already consumed (and re-zeroed) their rows: projecting all of [0, n) now would overwrite their gradients with zeros
+        g_last_error = "dvs_raster_backward_project: a dvs_raster_backward_project_chunk sequence is in progress on this context (finish it up to n)";
+        return DVS_ERR_STATE;
+    }
     HIPCHECK(hipSetDevice(c->device));
-    return bwd_project(c, (hipStream_t)stream, p, cam, opts, out, nullptr);
+    timing_reset(c);
+    StageTimer tm(c, (hipStream_t)stream);
+    if ((r = bwd_project(c, (hipStream_t)stream, p, cam, opts, out, &tm)) != DVS_OK) return r;
+    if (c->timing) { HIPCHECK(hipStreamSynchronize((hipStream_t)stream)); timing_collect(c, true); }
+    return DVS_OK;
 }
 
 int dvs_raster_backward_project_chunk(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cam, const dvs_opts* opts,
@@ -542,10 +565,15 @@ int dvs_raster_backward_project_chunk(dvs_ctx* c, void* stream, const dvs_splats
     const int V = c->n_views, n = p->n;
     DvsCams dcams;
     for (int v = 0; v < V; ++v) dcams.c[v] = to_dev_cam(cam[v]);
+    timing_reset(c);
+    StageTimer tm(c, (hipStream_t)stream);                                  // (every chunk is a "preprocess_bwd" row of the timing table)
+    const size_t t0 = tm.mark();
     HIPCHECK(dvs_launch_preprocess_bwd_views((hipStream_t)stream, n, V, p->pos, p->shN, p->opacity, p->scale, p->rot, dcams, opts->sh_degree,
                                              opts->antialias, s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->opacity, out->scale,
                                              out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, out->dcolor, opts->accumulate,
                                              c->keep_rows ? 0 : 1, opts->grad_mode, (int)first, (int)count));
+    { const size_t t1 = tm.mark(); tm.span("preprocess_bwd", t0, t1); }
+    if (c->timing) { HIPCHECK(hipStreamSynchronize((hipStream_t)stream)); timing_collect(c, true); }
     c->proj_next = first + count;
     if (c->proj_next == n) { c->rows_clean = !c->keep_rows; c->rows_pending = c->keep_rows; c->proj_next = 0; }
     return DVS_OK;
@@ -564,7 +592,7 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
     uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
     int cur = 0;
     HIPCHECK(dvs_launch_sort(st, k[0], v[0], k[1], v[1], n, bit_lo, bit_hi, c->sort_scratch.as<uint32_t>(), nullptr, 0,
-                             (unsigned long long*)(c->total_dev + 1), &cur));
+                             (unsigned long long*)(c->total_dev + 2), &cur));
     if (cur == 1) {
         HIPCHECK(hipMemcpyAsync(keys, k[1], n * 4, hipMemcpyDeviceToDevice, st));
         HIPCHECK(hipMemcpyAsync(vals, v[1], n * 4, hipMemcpyDeviceToDevice, st));
@@ -619,6 +647,12 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
     *T = c->total_host[0];
     c->st.num_rendered = *T;
+    if (c->total_host[2] != c->lookback_seen) {
+        c->lookback_seen = c->total_host[2];
+        g_last_error = "dvs_get_num_rendered: the chained-scan sort (DVS_SORT_ONESWEEP=1) ran out of look-back polls; the last forward's outputs "
+                       "are invalid — repeat it, or unset DVS_SORT_ONESWEEP.";
+        return DVS_ERR_STATE;
+    }
     if (c->total_host[1] != c->overflow_seen) {
         c->overflow_seen = c->total_host[1];
         (void)ensure_instance_arenas(c, *T + *T / 2);

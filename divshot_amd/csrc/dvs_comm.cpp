@@ -1,4 +1,5 @@
-// dvs_comm.cpp — include/dvs_comm.h: RCCL behind a plain-C surface (data-parallel exchange of the training step).
+// dvs_comm.cpp — include/dvs_comm.h: RCCL behind a plain-C surface (data-parallel exchange of the training step),
+// plus a host-staged TEST backend over the bootstrap sockets (DVS_COMM_BACKEND=tcp) so that two ranks can share one GPU in the test suite.
 // librccl is dlopen()ed on first use; the unique id travels from rank 0 to the other ranks over TCP on a dedicated bootstrap port.
 #include <hip/hip_runtime.h>
 #include <arpa/inet.h>
@@ -70,9 +71,10 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 // Bootstrap of the RCCL unique id over TCP. Rank 0 listens on the bootstrap port; every other rank connects (retrying while rank 0 is
-// not up yet), introduces itself with {magic, job nonce, rank} and gets {magic, id} back. Rank 0 serves every rank AT MOST ONCE and
-// keeps accepting until all world-1 distinct ranks have been served: a stray or stale connection (wrong magic / nonce / rank, or one
-// that sends nothing) is dropped without using up a slot. Every socket operation has a timeout and the whole exchange a deadline
+// not up yet), introduces itself with {magic, job nonce, rank}, gets {magic, id} back and acknowledges it. Rank 0 counts a rank once
+// (on its acknowledgement; a rank whose receive timed out may ask again while the listener is open) and keeps accepting until all
+// world-1 distinct ranks have acknowledged: a stray or stale connection (wrong magic / nonce / rank, or one that sends nothing) is
+// dropped without using up a slot, a hello with our magic but the wrong nonce is logged. Every socket operation has a timeout and the whole exchange a deadline
 // (DVS_COMM_TIMEOUT_S, default 180 s), after which it fails with an error instead of hanging.
 constexpr uint32_t kMagic = 0x44565343u;            // "DVSC"
 struct Hello { uint32_t magic; uint32_t rank; uint64_t nonce; };
@@ -85,8 +87,11 @@ void set_timeouts(int fd, int seconds) {
 }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-bool exchange_id(void* id128, int rank, int world, const char* addr, int port, uint64_t nonce, double timeout_s, std::string& err) {
+// keep_fds (TCP backend): the connections stay open — rank 0 gets one socket per peer (index = rank), a peer its socket to rank 0 at [0].
+bool exchange_id(void* id128, int rank, int world, const char* addr, int port, uint64_t nonce, double timeout_s, std::string& err,
+                 std::vector<int>* keep_fds = nullptr) {
     if (world == 1) return true;
+    if (keep_fds) keep_fds->assign(rank == 0 ? (size_t)world : 1u, -1);
     const double deadline = now_s() + timeout_s;
     if (rank == 0) {
         int ls = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -114,13 +119,23 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
             if (fd < 0) continue;                              // timeout tick / transient error
             set_timeouts(fd, 5);
             Hello h{};
-            const bool ok = recv_all(fd, &h, sizeof h) && h.magic == kMagic && h.nonce == nonce && h.rank >= 1 && h.rank < (uint32_t)world &&
-                            !served[h.rank];
+            const bool got = recv_all(fd, &h, sizeof h);
+            const bool ok = got && h.magic == kMagic && h.nonce == nonce && h.rank >= 1 && h.rank < (uint32_t)world;
+            bool kept = false;
             if (ok) {
+                // A rank that was served already may ask again (its 5 s receive can time out after our send_all returned): answer it
+                // again — it only counts once.
                 Reply r{}; r.magic = kMagic; memcpy(r.id, id128, 128);
-                if (send_all(fd, &r, sizeof r)) { served[h.rank] = true; --left; }
+                uint32_t ack = 0;                              // the peer confirms it holds the id: only then does its slot count
+                if (send_all(fd, &r, sizeof r) && recv_all(fd, &ack, sizeof ack) && ack == kMagic) {
+                    if (!served[h.rank]) { served[h.rank] = true; --left; }
+                    if (keep_fds) { int& slot = (*keep_fds)[h.rank]; if (slot >= 0) ::close(slot); slot = fd; kept = true; }
+                }
+            } else if (got && h.magic == kMagic) {
+                fprintf(stderr, "[dvs_comm] rank 0: dropped a hello from rank %u (%s) — do all ranks share MASTER_PORT / DVS_COMM_PORT and the run id?\n",
+                        h.rank, h.nonce != nonce ? "job nonce differs" : "rank outside the world");
             }
-            ::close(fd);                                       // (anything else: not one of ours, or a duplicate — no slot used)
+            if (!kept) ::close(fd);                            // (anything else: not one of ours — no slot used)
         }
         ::close(ls);
         return true;
@@ -137,8 +152,10 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
             if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
                 Hello h{}; h.magic = kMagic; h.rank = (uint32_t)rank; h.nonce = nonce;
                 Reply r{};
-                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic) { memcpy(id128, r.id, 128); ok = true; }
+                const uint32_t ack = kMagic;
+                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic && send_all(fd, &ack, sizeof ack)) { memcpy(id128, r.id, 128); ok = true; }
             }
+            if (ok && keep_fds) { (*keep_fds)[0] = fd; continue; }
             ::close(fd);
         }
         if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(100));
@@ -156,9 +173,11 @@ int bootstrap_port(int master_port) {
     if (port >= 65536) port = 1024 + (port - 65536) % (65536 - 1024);
     return port;
 }
-// Ranks of one job agree on a nonce without talking: the launcher's run id when there is one, else the rendezvous address itself.
-uint64_t job_nonce(const char* addr, int master_port) {
-    std::string key = std::string(addr ? addr : "") + ":" + std::to_string(master_port);
+// Ranks of one job agree on a nonce without talking: the rendezvous port plus the launcher's run id when there is one. The ADDRESS is
+// deliberately not part of it: rank 0 only listens, and may know the rendezvous host under another name (NULL, localhost, 127.0.0.1)
+// than the peers that connect to it.
+uint64_t job_nonce(const char* /*addr*/, int master_port) {
+    std::string key = ":" + std::to_string(master_port);
     for (const char* name : {"DVS_COMM_NONCE", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID"})
         if (const char* v = getenv(name)) { key += "|"; key += v; }
     uint64_t h = 1469598103934665603ull;                     // FNV-1a
@@ -174,7 +193,57 @@ double bootstrap_timeout() {
 struct dvs_comm {
     int device = 0, rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    // TEST-ONLY host-staged backend (DVS_COMM_BACKEND=tcp): a star over the bootstrap sockets. Rank 0 holds one socket per peer (index =
+    // rank), a peer its socket to rank 0 at [0]. Every collective is synchronous: wait for `stream`, copy to the host, exchange, reduce on
+    // rank 0 IN RANK ORDER (so every rank receives the same bits), copy back. It exists so that two ranks of the product can share the
+    // one GPU of a test box (RCCL cannot: both ranks would be the same device) — never a production path, and it says so when created.
+    bool tcp = false;
+    std::vector<int> fds;
+    std::vector<char> h_send, h_recv;
+    double op_timeout = 180.0;
 };
+
+namespace {
+int tcp_fail(const char* who, const char* what) {
+    dvs_set_last_error((std::string(who) + " (tcp backend): " + what).c_str());
+    return DVS_ERR_STATE;
+}
+// `bytes` of device memory at dev -> rank 0 combines the ranks' buffers with `combine(acc, incoming)` in rank order -> every rank gets
+// out_bytes back (reduce: out_bytes = bytes; gather: out_bytes = world * bytes, slot r = rank r's buffer).
+template <class Combine>
+int tcp_collective(dvs_comm* c, hipStream_t st, const void* dev_in, void* dev_out, size_t bytes, bool gather, Combine combine, const char* who) {
+    const size_t out_bytes = gather ? bytes * (size_t)c->world : bytes;
+    if (hipStreamSynchronize(st) != hipSuccess) return tcp_fail(who, "hipStreamSynchronize failed");
+    c->h_send.resize(bytes); c->h_recv.resize(out_bytes);
+    if (hipMemcpy(c->h_send.data(), dev_in, bytes, hipMemcpyDeviceToHost) != hipSuccess) return tcp_fail(who, "device -> host copy failed");
+    if (c->rank == 0) {
+        std::vector<char> in(bytes);
+        if (gather) memcpy(c->h_recv.data(), c->h_send.data(), bytes); else memcpy(c->h_recv.data(), c->h_send.data(), bytes);
+        for (int r = 1; r < c->world; ++r) {
+            if (!recv_all(c->fds[(size_t)r], in.data(), bytes)) return tcp_fail(who, "a peer closed its socket or timed out");
+            if (gather) memcpy(c->h_recv.data() + (size_t)r * bytes, in.data(), bytes);
+            else combine(c->h_recv.data(), in.data(), bytes);
+        }
+        for (int r = 1; r < c->world; ++r)
+            if (!send_all(c->fds[(size_t)r], c->h_recv.data(), out_bytes)) return tcp_fail(who, "send to a peer failed");
+    } else {
+        if (!send_all(c->fds[0], c->h_send.data(), bytes) || !recv_all(c->fds[0], c->h_recv.data(), out_bytes))
+            return tcp_fail(who, "rank 0 closed its socket or timed out");
+    }
+    if (hipMemcpy(dev_out, c->h_recv.data(), out_bytes, hipMemcpyHostToDevice) != hipSuccess) return tcp_fail(who, "host -> device copy failed");
+    return DVS_OK;
+}
+void sum_f32(char* acc, const char* in, size_t bytes) {
+    float* a = (float*)acc; const float* b = (const float*)in;
+    for (size_t i = 0; i < bytes / 4; ++i) a[i] += b[i];
+}
+void max_i32(char* acc, const char* in, size_t bytes) {
+    int32_t* a = (int32_t*)acc; const int32_t* b = (const int32_t*)in;
+    for (size_t i = 0; i < bytes / 4; ++i) a[i] = a[i] > b[i] ? a[i] : b[i];
+}
+void keep(char*, const char*, size_t) {}
+bool want_tcp_backend() { const char* b = getenv("DVS_COMM_BACKEND"); return b && std::string(b) == "tcp"; }
+}  // namespace
 
 #define RCCLCHECK(expr)                                                                                            \
     do {                                                                                                           \
@@ -211,6 +280,20 @@ dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_ad
     std::string err;
     resolve_rendezvous(rank, world, master_addr, master_port);
     if (rank < 0 || rank >= world) { dvs_set_last_error("dvs_comm_create: rank outside [0, world)"); return nullptr; }
+    if (want_tcp_backend()) {
+        if (hipSetDevice(device) != hipSuccess) { dvs_set_last_error("dvs_comm_create: hipSetDevice failed"); return nullptr; }
+        dvs_comm* c = new dvs_comm();
+        c->device = device; c->rank = rank; c->world = world; c->tcp = true; c->op_timeout = bootstrap_timeout();
+        char id[128] = {0};
+        if (!exchange_id(id, rank, world, master_addr, bootstrap_port(master_port), job_nonce(master_addr, master_port), bootstrap_timeout(), err, &c->fds)) {
+            dvs_set_last_error(("dvs_comm_create (tcp backend): " + err).c_str());
+            dvs_comm_destroy(c);
+            return nullptr;
+        }
+        for (int fd : c->fds) if (fd >= 0) { set_timeouts(fd, (int)c->op_timeout); int one = 1; setsockopt(fd, IPPROTO_TCP, 1 /*TCP_NODELAY*/, &one, sizeof one); }
+        fprintf(stderr, "[dvs_comm] rank %d of %d: DVS_COMM_BACKEND=tcp — host-staged TEST backend (no RCCL, no xGMI); never use it for measurements\n", rank, world);
+        return c;
+    }
     if (!g_rccl.load(err)) { dvs_set_last_error(("dvs_comm_create: " + err).c_str()); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { dvs_set_last_error("dvs_comm_create: hipSetDevice failed"); return nullptr; }
     ncclUniqueId id;
@@ -232,6 +315,7 @@ dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_ad
 
 void dvs_comm_destroy(dvs_comm* c) {
     if (!c) return;
+    for (int fd : c->fds) if (fd >= 0) ::close(fd);
     if (c->comm) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->comm); }
     delete c;
 }
@@ -241,40 +325,67 @@ int dvs_comm_world(const dvs_comm* c) { return c ? c->world : 1; }
 int dvs_comm_all_reduce_sum_f32(dvs_comm* c, void* stream, float* buf, size_t count) {
     if (!c || (count && !buf)) { dvs_set_last_error("dvs_comm_all_reduce_sum_f32: null argument"); return DVS_ERR_INVALID; }
     if (!count) return DVS_OK;
+    if (c->tcp) return c->world == 1 ? DVS_OK : tcp_collective(c, (hipStream_t)stream, buf, buf, count * 4, false, sum_f32, "dvs_comm_all_reduce_sum_f32");
     RCCLCHECK(g_rccl.AllReduce(buf, buf, count, rcclFloat32, rcclSum, c->comm, (hipStream_t)stream));
     return DVS_OK;
 }
 int dvs_comm_all_reduce_max_i32(dvs_comm* c, void* stream, int32_t* buf, size_t count) {
     if (!c || (count && !buf)) { dvs_set_last_error("dvs_comm_all_reduce_max_i32: null argument"); return DVS_ERR_INVALID; }
     if (!count) return DVS_OK;
+    if (c->tcp) return c->world == 1 ? DVS_OK : tcp_collective(c, (hipStream_t)stream, buf, buf, count * 4, false, max_i32, "dvs_comm_all_reduce_max_i32");
     RCCLCHECK(g_rccl.AllReduce(buf, buf, count, rcclInt32, rcclMax, c->comm, (hipStream_t)stream));
     return DVS_OK;
 }
 int dvs_comm_reduce_scatter_sum_f32(dvs_comm* c, void* stream, const float* send, float* recv, size_t recv_count) {
     if (!c || (recv_count && (!send || !recv))) { dvs_set_last_error("dvs_comm_reduce_scatter_sum_f32: null argument"); return DVS_ERR_INVALID; }
     if (!recv_count) return DVS_OK;
+    if (c->tcp) {          // all-reduce on the host, then this rank's slice
+        const size_t total = recv_count * (size_t)c->world;
+        float* tmp = nullptr;
+        if (hipMalloc((void**)&tmp, total * 4) != hipSuccess) return tcp_fail("dvs_comm_reduce_scatter_sum_f32", "hipMalloc failed");
+        int r = hipMemcpyAsync(tmp, send, total * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+        if (r == DVS_OK && c->world > 1) r = tcp_collective(c, (hipStream_t)stream, tmp, tmp, total * 4, false, sum_f32, "dvs_comm_reduce_scatter_sum_f32");
+        if (r == DVS_OK && hipMemcpy(recv, tmp + recv_count * (size_t)c->rank, recv_count * 4, hipMemcpyDeviceToDevice) != hipSuccess) r = DVS_ERR_HIP;
+        (void)hipFree(tmp);
+        return r;
+    }
     RCCLCHECK(g_rccl.ReduceScatter(send, recv, recv_count, rcclFloat32, rcclSum, c->comm, (hipStream_t)stream));
     return DVS_OK;
 }
 int dvs_comm_all_gather_f32(dvs_comm* c, void* stream, const float* send, float* recv, size_t send_count) {
     if (!c || (send_count && (!send || !recv))) { dvs_set_last_error("dvs_comm_all_gather_f32: null argument"); return DVS_ERR_INVALID; }
     if (!send_count) return DVS_OK;
+    if (c->tcp) {
+        if (c->world == 1) return hipMemcpyAsync(recv, send, send_count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+        return tcp_collective(c, (hipStream_t)stream, send, recv, send_count * 4, true, keep, "dvs_comm_all_gather_f32");
+    }
     RCCLCHECK(g_rccl.AllGather(send, recv, send_count, rcclFloat32, c->comm, (hipStream_t)stream));
     return DVS_OK;
 }
 int dvs_comm_group_start(dvs_comm* c) {
     if (!c) { dvs_set_last_error("dvs_comm_group_start: null communicator"); return DVS_ERR_INVALID; }
+    if (c->tcp) return DVS_OK;         // (each collective of the group runs on its own, in call order on every rank)
     RCCLCHECK(g_rccl.GroupStart());
     return DVS_OK;
 }
 int dvs_comm_group_end(dvs_comm* c) {
     if (!c) { dvs_set_last_error("dvs_comm_group_end: null communicator"); return DVS_ERR_INVALID; }
+    if (c->tcp) return DVS_OK;
     RCCLCHECK(g_rccl.GroupEnd());
     return DVS_OK;
 }
 int dvs_comm_broadcast(dvs_comm* c, void* stream, void* buf, size_t bytes, int root) {
     if (!c || (bytes && !buf) || root < 0 || root >= c->world) { dvs_set_last_error("dvs_comm_broadcast: bad argument"); return DVS_ERR_INVALID; }
     if (!bytes) return DVS_OK;
+    if (c->tcp) {          // gather everything on rank 0, keep the root's slot (test backend: simplicity over bytes)
+        if (c->world == 1) return DVS_OK;
+        char* tmp = nullptr;
+        if (hipMalloc((void**)&tmp, bytes * (size_t)c->world) != hipSuccess) return tcp_fail("dvs_comm_broadcast", "hipMalloc failed");
+        int r = tcp_collective(c, (hipStream_t)stream, buf, tmp, bytes, true, keep, "dvs_comm_broadcast");
+        if (r == DVS_OK && hipMemcpy(buf, tmp + bytes * (size_t)root, bytes, hipMemcpyDeviceToDevice) != hipSuccess) r = DVS_ERR_HIP;
+        (void)hipFree(tmp);
+        return r;
+    }
     RCCLCHECK(g_rccl.Broadcast(buf, buf, bytes, rcclUint8, root, c->comm, (hipStream_t)stream));
     return DVS_OK;
 }

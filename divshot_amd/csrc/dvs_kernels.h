@@ -34,10 +34,13 @@ hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, floa
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort needs for up to n items.
 size_t dvs_sort_scratch_words(uint64_t n);
-// Stable LSD radix sort (8-bit digits) of (key, value) pairs over key bits [bit_lo, bit_hi): one histogram kernel + one sweep kernel
-// per pass (chained-scan partition prefixes). Buffers 0 hold the input; *result_in = index (0 / 1) of the buffer pair with the result.
+// Stable LSD radix sort (8-bit digits) of (key, value) pairs over key bits [bit_lo, bit_hi). Default: three kernels per pass (per-
+// partition digit histogram, row scan of the histograms, scatter). DVS_SORT_ONESWEEP=1 selects the chained-scan form (one global
+// histogram kernel + one sweep kernel per pass; bit-exact, measured slower on MI355X; n < 2^30 only, larger sorts take the default).
+// Buffers 0 hold the input; *result_in = index (0 / 1) of the buffer pair with the result.
 // n_dev (nullable): the item count lives on the device (min(*n_dev, n) items are sorted; n bounds it) — no host round trip for T;
-// n_expected: grid hint for it. err_counter: device counter raised if the chained scan runs out of polls (outputs then invalid).
+// n_expected: grid hint for it. err_counter: device counter raised ONLY by the chained-scan form when a look-back runs out of polls
+// (outputs then invalid; the host reports it as a broken look-back chain, see dvs_api.cpp).
 hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, uint64_t n, int bit_lo, int bit_hi,
                            uint32_t* scratch, const uint64_t* n_dev, uint64_t n_expected, unsigned long long* err_counter, int* result_in);
 // A3: gathers the tile rectangles (4 x u16 per splat, written by A2) into depth order, offsets over their areas. Writes block offsets

@@ -916,7 +916,11 @@ hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, c
     if (i1 <= i0) return hipSuccess;
     const int grid = (i1 - i0 + PP_BLOCK - 1) / PP_BLOCK;
     const size_t lds = (size_t)PP_BLOCK * 6 * sizeof(float);
-    static const bool nohoist = getenv("DVS_A9V_NOHOIST") && getenv("DVS_A9V_NOHOIST")[0] == '1';
+#ifdef DVS_EXPERIMENT
+    static const bool nohoist = getenv("DVS_A9V_NOHOIST") && getenv("DVS_A9V_NOHOIST")[0] == '1';      // experiment builds only
+#else
+    constexpr bool nohoist = false;
+#endif
 #define DVS_PPV1(A, N)                                                                                                          \
     hipLaunchKernelGGL((k_preprocess_bwd_views<A, N>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
                        deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_opacity, g_scale, g_rot,                         \

@@ -381,7 +381,8 @@ __global__ void __launch_bounds__(RB)
 k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
                 const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
-                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage, int dbg) {
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage, int dbg_arg /*experiment builds: ablation bits*/) {
+    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;
     __shared__ BatchLds L;
     __shared__ uint32_t s_max[RB / 64];
     __shared__ __attribute__((aligned(16))) float2 s_pair[RB / 64][MM_SLOTS * MM_STRIDE];   // per wave: [slot][pixel] (v5, w); epilogue scratch
@@ -590,7 +591,7 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
     // experiment knobs (tools/bwd_probe.py): extra dynamic LDS to lower the occupancy, debug bits that drop parts of the mm kernel
-    static const int dbg = [] { const char* e = getenv("DVS_MM_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int dbg = dvs_experiment_int("DVS_MM_DEBUG");
     const size_t extra_lds = dvs_experiment_extra_lds();
     if (variant == DVS_BWD_REDUCE) {
 #define DVS_RB(KERNEL)                                                                                                             \

@@ -5,9 +5,21 @@
 
 #define RB 256
 
+// Timing-only ablation knobs (DVS_TR_DEBUG, DVS_MM_DEBUG, DVS_A9V_NOHOIST, DVS_BWD_EXTRA_LDS) exist only in experiment builds
+// (-DDVS_EXPERIMENT, tools/xbuild.sh): the release library neither reads those variables nor carries the code they select
+// (tests/test_abi.py::test_release_build_has_no_ablation_knobs). DVS_EXPERIMENT_ON folds the knob tests away at compile time.
+#ifdef DVS_EXPERIMENT
+#define DVS_EXPERIMENT_ON 1
+#else
+#define DVS_EXPERIMENT_ON 0
+#endif
+
 // Experiment knob of the occupancy measurements (tools/bwd_probe.py): DVS_BWD_EXTRA_LDS = bytes of dynamic LDS added to the composite
 // backward launches so that fewer workgroups fit a CU. Read ONCE per process and clamped to what a launch can carry.
 static inline size_t dvs_experiment_extra_lds() {
+#ifndef DVS_EXPERIMENT
+    return 0;
+#else
     static const size_t v = [] {
         const char* e = getenv("DVS_BWD_EXTRA_LDS");
         long x = e ? atol(e) : 0;
@@ -16,6 +28,17 @@ static inline size_t dvs_experiment_extra_lds() {
         return (size_t)x;
     }();
     return v;
+#endif
+}
+// An integer knob of an experiment build (0 in release builds, where the variable is not read at all).
+static inline int dvs_experiment_int(const char* name) {
+#ifdef DVS_EXPERIMENT
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
 }
 
 // Per-view backgrounds of a multi-view batch: FIRST kernel parameter of the composite kernels, read through the kernarg segment

@@ -142,13 +142,14 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
                 int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
                 const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
-                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg /*experiment knobs (timing only)*/,
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg_arg /*experiment builds: ablation bits (timing only)*/,
                 const uint32_t* __restrict__ live_splat /*k_render_fwd's compacted lists (entries that reach the tile), or null*/,
                 const uint32_t* __restrict__ live_pos /*list position -> position in the compacted list*/) {
     __shared__ TrLds<BK> L;
     __shared__ float s_tab[4][(BK + 1) * 12];               // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
     __shared__ __attribute__((aligned(16))) float s_tb[4][TR_SLOTS * TR_SS];  // per wave: slot, plane (v5 | w), phase-1 lane
     (void)bg_arg;
+    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;       // release builds: every `dbg &` test below folds away
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
     if (tile_g >= num_tiles) return;
     const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
@@ -395,7 +396,7 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
-    static const int dbg = [] { const char* e = getenv("DVS_TR_DEBUG"); return e ? atoi(e) : 0; }();      // ablation knobs of tools/bwd_probe.py (timing only)
+    static const int dbg = dvs_experiment_int("DVS_TR_DEBUG");      // ablation bits of tools/bwd_probe.py (timing only; experiment builds)
     const size_t extra_lds = dvs_experiment_extra_lds();
 #define DVS_TR(A, LN, BKV)                                                                                                          \
     hipLaunchKernelGGL((k_render_bwd_tr<A, LN, BKV>), dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, \

@@ -98,7 +98,9 @@ struct GaussianTrainerScene::Impl {
     float* d_dcolor_scratch = nullptr;                                       // A9's own copy of the colour gradient (the all-gather reads the early one)
     hipStream_t comm_stream = nullptr; hipEvent_t ev_dcolor = nullptr, ev_bwd = nullptr, ev_comm = nullptr;   // collectives run beside A9
     hipEvent_t ev_gather = nullptr; std::vector<hipEvent_t> ev_chunk;        // all-gather done / A9 chunk k queued (chunked geometry all-reduce)
-    int a9_chunks = 4;                                                       // DVS_A9_CHUNKS: splat chunks of A9 whose geometry gradients leave one by one
+    int a9_chunks = 1;                                                       // DVS_A9_CHUNKS: splat chunks of A9 whose geometry gradients leave one by one (default 1 until
+                                                                             // the chunked exchange has run on real multi-GPU hardware: ADVICE r03; equality with the unchunked
+                                                                             // exchange is asserted by tests/test_gpu_multirank.py::test_plugin_two_ranks_exchanges_agree)
     std::vector<uint8_t*> d_targets_u8; float* d_target_f32 = nullptr;       // packLevel & PackF32ToU8
     std::vector<float*> d_masks;                                             // useMask
     std::vector<float> init_host[6];                                         // initial splats (resetGaussian, getPoints3D)
@@ -504,7 +506,9 @@ GaussianTrainerScene::GaussianTrainerScene(const GaussianTrainConfig& cfg, int l
         if (!impl_->comm) throw std::runtime_error(std::string("gstrain: dvs_comm_create failed: ") + dvs_last_error());
         impl_->rank = dvs_comm_rank(impl_->comm); impl_->world = dvs_comm_world(impl_->comm);
         if (const char* ex = getenv("DVS_EXCHANGE")) impl_->factorised = std::string(ex) != "allreduce";
-        logf_("rank %d of %d on device %d: RCCL communicator up, gradient exchange: %s", impl_->rank, impl_->world, impl_->device,
+        const char* be = getenv("DVS_COMM_BACKEND");
+        logf_("rank %d of %d on device %d: %s communicator up, gradient exchange: %s", impl_->rank, impl_->world, impl_->device,
+              be && std::string(be) == "tcp" ? "host-staged TCP (TEST backend)" : "RCCL",
               impl_->factorised ? "factorised (all-gather of colour gradients + all-reduce of 44 B/splat)" : "all-reduce of all rows");
     }
 }
@@ -763,9 +767,12 @@ void GaussianTrainerScene::trainStep() {
 
 void GaussianTrainerScene::saveGaussianModel() {
     Impl& m = *impl_;
-    if (m.rank != 0) return;                 // the replicas are identical: one file
+    // the replicas are identical: one file — unless DVS_SAVE_ALL_RANKS=1 asks every rank for its own (<model>_<it>.ply.rank<r>), which
+    // is how the two-rank test checks that they ARE identical, bit for bit
+    static const bool all_ranks = [] { const char* e = getenv("DVS_SAVE_ALL_RANKS"); return e && e[0] == '1'; }();
+    if (m.rank != 0 && !all_ranks) return;
     m.fetch_host();
-    const std::string file = m.model_file(m.step);
+    const std::string file = m.model_file(m.step) + (m.rank != 0 ? ".rank" + std::to_string(m.rank) : std::string());
     std::error_code ec;
     const auto parent = std::filesystem::path(file).parent_path();
     if (!parent.empty()) std::filesystem::create_directories(parent, ec);

@@ -12,6 +12,11 @@
  * on a DEDICATED port (the launcher's own store already listens on MASTER_PORT): DVS_COMM_PORT if set, else MASTER_PORT + 1789. A
  * peer introduces itself with {magic, job nonce, rank}; rank 0 serves every rank at most once, ignores anything else, and every
  * step has a timeout (DVS_COMM_TIMEOUT_S, default 180 s: an error, never a hang). Plain C, int status codes as dvs_raster.h.
+ *
+ * DVS_COMM_BACKEND=tcp selects a TEST-ONLY backend: the same calls, executed host-staged over the bootstrap sockets (star on rank 0,
+ * sums formed in rank order, every call synchronous). It needs neither librccl nor distinct devices per rank, which is the point: two
+ * ranks of libgstrain.so can share the one GPU of a test box (tests/test_gpu_multirank.py). It is announced on stderr when created and
+ * must never be used for measurements.
  */
 #ifndef DVS_COMM_H
 #define DVS_COMM_H

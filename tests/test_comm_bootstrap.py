@@ -48,7 +48,7 @@ def test_three_ranks_next_to_a_busy_master_port_with_strays():
     store = socket.socket(); store.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     store.bind(("127.0.0.1", port)); store.listen(4)          # the launcher's own store occupies MASTER_PORT
     boot = port + 1789 if port + 1789 < 65536 else 1024 + (port + 1789 - 65536) % (65536 - 1024)
-    r0 = _spawn(0, 3, port)
+    r0 = _spawn(0, 3, port, {"MASTER_ADDR": "localhost"})      # rank 0 only listens: it may know the host under another name
     # strays on the bootstrap port while rank 0 waits: garbage, a silent connection, and a well-formed hello of the wrong job
     deadline = time.time() + 30
     while True:

@@ -220,3 +220,20 @@ def test_sharded_adam_gloo():
         assert p.exitcode == 0
     sums = dict(out.get(timeout=5) for _ in range(world))
     assert abs(sums[0] - sums[1]) < 1e-3                            # identical replicas after the all-gather
+
+
+def test_bench_watchdog_turns_a_hang_into_an_error_line():
+    """`python bench.py --gpus 2` whose ranks never come back (DVS_BENCH_TEST_HANG: they sleep before touching a GPU): after
+    DVS_BENCH_WATCHDOG_S the run ends with ONE JSON line carrying "error" and value null, and a non-zero exit code — not with the
+    caller's own 1800-s limit. Runs on CPU: the hang sits before any device work."""
+    import json, subprocess, sys, time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DVS_BENCH_TEST_HANG="1", DVS_BENCH_WATCHDOG_S="30")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=240, env=env, cwd=ROOT)
+    assert p.returncode != 0 and time.time() - t0 < 150
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:] + p.stderr[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and "watchdog" in rec["error"] and rec["n_gpus"] == 2
