@@ -203,6 +203,9 @@ def main():
                     help="1: capture the step (one multi-view pass forward + loss gradient + backward) into a HIP graph after the warm-up and "
                          "replay it (one GPU, --mode batch, asynchronous forward: the pass has no host synchronisation and fixed launch shapes)")
     ap.add_argument("--async-forward", type=int, default=1, help="1: dvs_set_async — the forward never synchronises the host (T stays on the device)")
+    ap.add_argument("--tight-tiles", type=int, default=0,
+                    help="1: dvs_opts.tile_bounds = DVS_TILES_TIGHT (opt-in: only the tiles the alpha >= 1/255 ellipse reaches; same images and "
+                         "gradients, shorter lists). The headline (default 0) runs the canonical 3-sigma rectangles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10, help="extra iterations with per-stage hipEvent timing")
     args = ap.parse_args()
@@ -359,7 +362,7 @@ def main():
                     st.wait_event(step_done)       # no overlap across steps: the next step's views see updated parameters
                 if n_ctx > 1 and args.stagger and gi > 0:
                     st.wait_event(fwd_done[(gi - 1) % n_ctx])
-                imgs = rasts[c].forward_views(params, cams_group[gi], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled,
+                imgs = rasts[c].forward_views(params, cams_group[gi], sh_degree=deg, absgrad=bool(args.absgrad), out=outs[c], shn_tiled=tiled, tight_tiles=bool(args.tight_tiles),
                                               grad_mode=gm["mode"])
                 if n_ctx > 1:
                     fwd_done[c].record(st)
@@ -498,7 +501,7 @@ def main():
     rast1 = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
     rast1.set_backward_variant(args.bwd_variant); rast1.set_forward_variant(args.fwd_variant); rast1.set_async(bool(args.async_forward))
     if rank == 0:
-        rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode)
+        rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode, tight_tiles=bool(args.tight_tiles))
     # ---- strict single-view figure of SURVEY.md §8(d): 1 / (t_fwd + t_bwd), one view at a time on one stream, no pipelining ----
     strict = None
     if rank == 0 and args.profile_iters > 0:
@@ -508,7 +511,7 @@ def main():
         for it_ in range(n_strict + 5):
             if it_ == 5:
                 ev0.record(main_stream)
-            img = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode)
+            img = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, grad_mode=args.grad_mode, tight_tiles=bool(args.tight_tiles))
             dL = torch.add(neg_targets_scaled[0], img, alpha=inv_P)
             rast1.backward(dL, grads=g_strict)
         ev1.record(main_stream)
@@ -554,7 +557,7 @@ def main():
         rast1.enable_timing(True)
         acc = {}
         for _ in range(args.profile_iters):
-            img = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled)
+            img = rast1.forward(params, cam, sh_degree=deg, absgrad=bool(args.absgrad), out=out, shn_tiled=tiled, tight_tiles=bool(args.tight_tiles))
             dL = (img - target) * inv_P
             rast1.backward(dL, grads={k: v for k, v in grads.items() if k != "dcolor"})
             for k, v in rast1.stage_timing().items():
@@ -716,7 +719,7 @@ def main():
                                    + (f" as {K} multi-view pass(es) of {G} view(s) (dvs_raster_forward_views / dvs_raster_backward_*)"
                                       + (" software-pipelined over two contexts/streams, gradients accumulated" if K > 1 else ""))
                                    + ((", RCCL exchange of the gradient rows: " + exchange) if world > 1 else ""),
-                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "stagger": bool(args.stagger), "groups": K, "views_per_group": G, "early_gather": bool(early), "a9_chunks": len(a9_chunks) if a9_chunks else 1, "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
+                       "views_per_step": world * VPS, "views_per_gpu_per_step": VPS, "ms_per_view": ms_per_step / VPS, "absgrad": bool(args.absgrad), "mode": args.mode, "stagger": bool(args.stagger), "groups": K, "views_per_group": G, "early_gather": bool(early), "a9_chunks": len(a9_chunks) if a9_chunks else 1, "async_forward": bool(args.async_forward), "hip_graph": bool(args.graph), "bwd_variant": args.bwd_variant, "fwd_variant": args.fwd_variant, "grad_mode": args.grad_mode, "tile_bounds": "tight (opt-in)" if args.tight_tiles else "canonical", "shN_layout": "tiled[N/64][45][64]" if tiled else "rows[N][45]",
                        "N": n, "V": V, "T": T, "P": Ppix, "tiles": tiles, "sort_passes_p": p},
             "grad_l2_after_exchange": grad_norms,
             "roofline": roofline,

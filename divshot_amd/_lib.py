@@ -31,7 +31,7 @@ class Camera(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("sh_degree", C.c_int32), ("antialias", C.c_int32), ("absgrad", C.c_int32), ("accumulate", C.c_int32),
-                ("shn_layout", C.c_int32), ("grad_mode", C.c_int32), ("_reserved", C.c_int32 * 2)]
+                ("shn_layout", C.c_int32), ("grad_mode", C.c_int32), ("tile_bounds", C.c_int32), ("_reserved", C.c_int32 * 1)]
 
 
 class FwdState(C.Structure):

@@ -504,6 +504,13 @@ hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uin
 __device__ __forceinline__ uint32_t rect_tiles(uint2 r) {
     return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));
 }
+// DVS_TILES_TIGHT: a splat's instances = the set bits of its 64-bit tile mask (all ones: the whole rectangle — rectangles of more than 64
+// tiles are never tightened)
+__device__ __forceinline__ uint32_t rect16_tiles(uint4 r) {
+    const uint32_t both = r.z & r.w;
+    return both == 0xFFFFFFFFu ? rect_tiles(make_uint2(r.x, r.y)) : (uint32_t)(__popc(r.z) + __popc(r.w));
+}
+template <bool TIGHT>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted,
                 uint32_t* __restrict__ block_sums) {
@@ -511,9 +518,15 @@ k_tile_blocksum(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __r
     const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
     uint32_t v = 0;
     if (j < n) {
-        const uint2 r = rect[sorted_ids[j]];
-        rect_sorted[j] = r;
-        v = rect_tiles(r);
+        if (TIGHT) {
+            const uint4 r = reinterpret_cast<const uint4*>(rect)[sorted_ids[j]];
+            reinterpret_cast<uint4*>(rect_sorted)[j] = r;
+            v = rect16_tiles(r);
+        } else {
+            const uint2 r = rect[sorted_ids[j]];
+            rect_sorted[j] = r;
+            v = rect_tiles(r);
+        }
     }
     uint32_t tot;
     (void)block_excl_scan(v, tmp, &tot);
@@ -559,9 +572,10 @@ k_tile_scan_blocks(uint32_t* __restrict__ block_sums, uint32_t num_blocks, uint6
 size_t dvs_scan_scratch_words(int n) { return (size_t)((n + SORT_BLOCK - 1) / SORT_BLOCK) + 1; }
 
 hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect, uint32_t* rect_sorted,
-                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity) {
+                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity, int tight) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
-    if (nb > 0) hipLaunchKernelGGL(k_tile_blocksum, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect, (uint2*)rect_sorted, block_offsets);
+    if (nb > 0 && tight) hipLaunchKernelGGL(k_tile_blocksum<true>, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect, (uint2*)rect_sorted, block_offsets);
+    else if (nb > 0) hipLaunchKernelGGL(k_tile_blocksum<false>, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect, (uint2*)rect_sorted, block_offsets);
     hipLaunchKernelGGL(k_tile_scan_blocks, dim3(1), dim3(SCANB_THREADS), 0, st, block_offsets, nb, total_dev, capacity);
     return hipGetLastError();
 }
@@ -573,6 +587,19 @@ hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_id
 // the 64 exclusive offsets (LDS) and its tile from the slot's index inside the splat's rectangle (row-major), so that a store
 // instruction covers 64 consecutive instances whatever the rectangle sizes are. (Rounds 1-2 let the owning lane loop over a small
 // rectangle: the 64 lanes then wrote 64 different runs per instruction, 1.9 TB/s of stores.)
+// position of the (t + 1)-th set bit of a 64-bit mask (t < popcount): the tile index of instance t of a tightened rectangle
+__device__ __forceinline__ uint32_t nth_set_bit64(uint32_t lo, uint32_t hi, uint32_t t) {
+    uint32_t w = lo, base = 0;
+    const uint32_t c = (uint32_t)__popc(lo);
+    if (t >= c) { t -= c; w = hi; base = 32u; }
+#pragma unroll
+    for (uint32_t h = 16u; h >= 1u; h >>= 1) {
+        const uint32_t cl = (uint32_t)__popc(w & ((1u << h) - 1u));
+        if (t >= cl) { t -= cl; w >>= h; base += h; }
+    }
+    return base;
+}
+template <bool TIGHT>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rect_sorted,
             const uint32_t* __restrict__ block_offsets, int tiles_x, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat,
@@ -582,10 +609,16 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restr
     __shared__ uint32_t s_id[SORT_BLOCK];
     __shared__ uint32_t s_tile[SORT_BLOCK];         // tile id of the rectangle's first tile (view offset included)
     __shared__ uint32_t s_w[SORT_BLOCK];            // rectangle width in tiles
+    __shared__ uint2 s_mask[TIGHT ? SORT_BLOCK : 1]; // DVS_TILES_TIGHT: the splat's tile mask
     const int j = blockIdx.x * SORT_BLOCK + threadIdx.x;
     uint32_t id = 0, touched = 0;
     uint2 r = make_uint2(0u, 0u);
-    if (j < n) { id = sorted_ids[j]; r = rect_sorted[j]; touched = rect_tiles(r); }
+    if (TIGHT) {
+        uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
+        if (j < n) { id = sorted_ids[j]; r4 = reinterpret_cast<const uint4*>(rect_sorted)[j]; touched = rect16_tiles(r4); }
+        r = make_uint2(r4.x, r4.y);
+        s_mask[threadIdx.x] = make_uint2(r4.z, r4.w);
+    } else if (j < n) { id = sorted_ids[j]; r = rect_sorted[j]; touched = rect_tiles(r); }
     // multi-view batch: the sort value is the global index view * n_per_view + splat; the tile ids of view v start at v * tiles_per_view
     uint32_t view = 0;
     for (int k = 1; k < n_views; ++k) view += (id >= (uint32_t)k * (uint32_t)n_per_view) ? 1u : 0u;
@@ -606,7 +639,12 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restr
 #pragma unroll
         for (uint32_t step = 32u; step >= 1u; step >>= 1)
             if (s_pre[w0 + lo + step] <= k) lo += step;
-        const uint32_t src = w0 + lo, t = k - s_pre[src], w = s_w[src];
+        const uint32_t src = w0 + lo, w = s_w[src];
+        uint32_t t = k - s_pre[src];
+        if (TIGHT) {                                          // instance t of the splat = its (t + 1)-th surviving tile
+            const uint2 m = s_mask[src];
+            if ((m.x & m.y) != 0xFFFFFFFFu) t = nth_set_bit64(m.x, m.y, t);
+        }
         // row = t / w by a float quotient and one correction step (t < 2^24: a rectangle has fewer tiles than the screen)
         uint32_t q = (uint32_t)((float)t * __builtin_amdgcn_rcpf((float)w));
         int32_t rem = (int32_t)(t - q * w);
@@ -621,11 +659,13 @@ k_duplicate(int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restr
 
 hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
                                 const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity,
-                                int n_per_view, int n_views, int tiles_per_view) {
+                                int n_per_view, int n_views, int tiles_per_view, int tight) {
     const uint32_t nb = (uint32_t)((n + SORT_BLOCK - 1) / SORT_BLOCK);
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect_sorted, block_offsets,
-                       tiles_x, inst_tile, inst_splat, capacity, n_per_view, n_views, tiles_per_view);
+    if (tight) hipLaunchKernelGGL(k_duplicate<true>, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect_sorted, block_offsets,
+                                  tiles_x, inst_tile, inst_splat, capacity, n_per_view, n_views, tiles_per_view);
+    else hipLaunchKernelGGL(k_duplicate<false>, dim3(nb), dim3(SORT_BLOCK), 0, st, n, sorted_ids, (const uint2*)rect_sorted, block_offsets,
+                            tiles_x, inst_tile, inst_splat, capacity, n_per_view, n_views, tiles_per_view);
     return hipGetLastError();
 }
 

@@ -143,7 +143,7 @@ int ensure_splat_arenas(dvs_ctx* c, size_t n) {
     int r;
 #define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
     ENS(radii, n * 4) ENS(splat2d, n * 64) ENS(depth, n * 4)
-    ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(rect, n * 8) ENS(rect_sorted, n * 8) ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
+    ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(rect, n * 16) ENS(rect_sorted, n * 16)     /* 8 B per (view, splat) canonically; 16 B with DVS_TILES_TIGHT (rectangle + tile mask) */ ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
     ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
     ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)
     ENS(g_rows, n * 48)
@@ -244,6 +244,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     c->rows_pending = false;
     timing_reset(c);
     StageTimer tm(c, st);
+    const int tight = opts->tile_bounds == DVS_TILES_TIGHT ? 1 : 0;      // opt-in: only the tiles the alpha >= 1/255 ellipse reaches (dvs_raster.h)
 
     // A2 preprocess: one lane per splat, all views
     size_t e0 = tm.mark();
@@ -251,7 +252,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
                                        opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
                                        c->depth.as<float>(),
                                        c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
-                                       c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>()));
+                                       c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>(), tight ? c->rect.as<uint32_t>() : nullptr));
     size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
     // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
     int cur = 0;
@@ -291,7 +292,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         T_expected = lastT > 0 ? lastT + lastT / 16 + 4096 : 0;      // grid size only: the kernels stride over whatever T turns out to be
     }
     HIPCHECK(dvs_launch_tile_scan(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
-                                  c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull));
+                                  c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull, tight));
     HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 32, hipMemcpyDeviceToHost, st));
     size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
     if (!c->async_T) {
@@ -304,7 +305,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     // A4 duplicate
     size_t e4 = tm.mark();
     HIPCHECK(dvs_launch_duplicate(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect_sorted.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
-                                  tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap, n, V, tiles));
+                                  tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap, n, V, tiles, tight));
     size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
     // A5 (high key bits): sort by (view, tile) over the instances
     int icur = 0;
@@ -357,8 +358,9 @@ static int check_fwd_args(dvs_ctx* c, const dvs_splats* p, const dvs_camera* cam
     if (V < 1 || V > c->max_views) { g_last_error = "dvs_raster_forward: n_views exceeds the max_views given to dvs_create_views"; return DVS_ERR_CAPACITY; }
     const dvs_camera* cam = &cams[0];
     if (p->n < 0 || cam->width <= 0 || cam->height <= 0 || opts->sh_degree < 0 || opts->sh_degree > 3 ||
-        (opts->shn_layout != DVS_SHN_ROWS && opts->shn_layout != DVS_SHN_TILED)) {
-        g_last_error = "dvs_raster_forward: bad n / image size / sh_degree"; return DVS_ERR_INVALID;
+        (opts->shn_layout != DVS_SHN_ROWS && opts->shn_layout != DVS_SHN_TILED) ||
+        (opts->tile_bounds != DVS_TILES_CANONICAL && opts->tile_bounds != DVS_TILES_TIGHT)) {
+        g_last_error = "dvs_raster_forward: bad n / image size / sh_degree / shn_layout / tile_bounds"; return DVS_ERR_INVALID;
     }
     for (int v = 1; v < V; ++v)
         if (cams[v].width != cam->width || cams[v].height != cam->height) { g_last_error = "dvs_raster_forward: the views of a batch must share one image size"; return DVS_ERR_INVALID; }

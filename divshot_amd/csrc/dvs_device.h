@@ -87,6 +87,72 @@ __device__ __forceinline__ float dvs_exp_det(float x) {
 __device__ __forceinline__ float dvs_sqrt_rn(float x) { return sqrtf(x); }
 __device__ __forceinline__ float dvs_sigmoid_det(float x) { return 1.0f / (1.0f + dvs_exp_det(-x)); }
 
+// Deterministic natural logarithm for x > 0 (normal numbers): a fixed sequence of IEEE-exact operations, like dvs_exp_det — it feeds an
+// integer decision (which tiles a splat is binned into with DVS_TILES_TIGHT), so the CPU oracle must reproduce it bit for bit.
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = 2 t (1 + t^2/3 + t^4/5 + t^6/7 + t^8/9), t = (m - 1) / (m + 1), |t| < 0.172:
+// truncation below 1e-9.
+__device__ __forceinline__ float dvs_log_det(float x) {
+    const uint32_t bits = __float_as_uint(x);
+    int e = (int)(bits >> 23) - 127;
+    float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float t2 = t * t;
+    float p = 0.111111111f;
+    p = __builtin_fmaf(p, t2, 0.142857143f);
+    p = __builtin_fmaf(p, t2, 0.2f);
+    p = __builtin_fmaf(p, t2, 0.333333333f);
+    p = __builtin_fmaf(p, t2, 1.0f);
+    return __builtin_fmaf((float)e, 0.693147181f, (2.0f * t) * p);
+}
+
+// DVS_TILES_TIGHT (dvs_raster.h): which tiles of a splat's 3-sigma rectangle its alpha >= 1/255 ellipse can reach. Bit t of the result =
+// tile t of the rectangle in row-major order (area <= 64). The minimum of the conic form q(d) = a dx^2 + 2 b dx dy + c dy^2 over the
+// tile's pixel-centre rectangle [16 tx, 16 tx + 15] x [16 ty, 16 ty + 15] is 0 if the mean lies inside, otherwise it lies on an edge
+// facing the mean; on the vertical line x: q = c (y - y*)^2 + x^2 det / c with y* = -b x / c — non-negative terms only (see
+// render.hip stage_batch), det lowered by its rounding bound. The tile stays unless q_min > 2 ln(o / ((1/255)(1 - 1e-3))), i.e. unless
+// even the nearest point of the tile stays below alpha = (1/255)(1 - 1e-3): the margin (2e-3 in q) covers the rounding of q_min, of
+// dvs_log_det and of the per-pixel alpha in the composite kernels, so no contributing pixel can lose its splat.
+// EVERY operation is IEEE-exact and in a fixed order (this file is compiled with -ffp-contract=off): the CPU oracle
+// (oracle/dvs_oracle.hpp tight_tile_mask) evaluates the same sequence and reproduces the mask bit for bit.
+#define DVS_TIGHT_LOG_INV_ALPHA 5.5422648f       /* -ln((1/255)(1 - 1e-3)) */
+__device__ __forceinline__ unsigned long long dvs_tight_tile_mask(float a, float b, float c, float o, float mx, float my, int rminx, int rminy,
+                                                                  int rmaxx, int rmaxy) {
+    const float ac = a * c;
+    const float det = fmaxf(0.f, __builtin_fmaf(-2.4e-7f, ac, ac - b * b));
+    const float inv_c = 1.0f / c, inv_a = 1.0f / a;
+    const float det_c = det * inv_c, det_a = det * inv_a, nb_c = -b * inv_c, nb_a = -b * inv_a;
+    const float kappa = 2.0f * (dvs_log_det(o) + DVS_TIGHT_LOG_INV_ALPHA);
+    unsigned long long mask = 0ull;
+    int t = 0;
+    for (int ty = rminy; ty < rmaxy; ++ty) {
+        const float y0 = (float)(ty * DVS_TILE) - my, y1 = y0 + (float)(DVS_TILE - 1);
+        const bool hin = y0 <= 0.f && y1 >= 0.f;
+        const float ye = y0 > 0.f ? y0 : y1;
+        const float hx = nb_a * ye, hbase = (ye * ye) * det_a;
+        for (int tx = rminx; tx < rmaxx; ++tx, ++t) {
+            const float x0 = (float)(tx * DVS_TILE) - mx, x1 = x0 + (float)(DVS_TILE - 1);
+            const bool vin = x0 <= 0.f && x1 >= 0.f;
+            float qmin = 0.f;
+            if (!(vin && hin)) {
+                qmin = __builtin_inff();
+                if (!vin) {
+                    const float xe = x0 > 0.f ? x0 : x1;
+                    const float vy = nb_c * xe;
+                    const float d = fminf(fmaxf(vy, y0), y1) - vy;
+                    qmin = (c * d) * d + (xe * xe) * det_c;
+                }
+                if (!hin) {
+                    const float d = fminf(fmaxf(hx, x0), x1) - hx;
+                    qmin = fminf(qmin, (a * d) * d + hbase);
+                }
+            }
+            mask |= !(qmin > kappa) ? (1ull << t) : 0ull;         // NaN-safe: a failed comparison keeps the tile
+        }
+    }
+    return mask;
+}
+
 __device__ __forceinline__ float dvs_xform(const float* m, float x, float y, float z, int r) {
     return ((m[0 * 4 + r] * x + m[1 * 4 + r] * y) + m[2 * 4 + r] * z) + m[3 * 4 + r];
 }

@@ -9,7 +9,8 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCams& cams, int n_views,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii /*per-view outputs are [n_views][n]*/, float* splat2d,
                                      float* depth, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect /*[n,2]: 4 x u16*/);
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect /*[n,2]: 4 x u16*/,
+                                     uint32_t* rect16 /*DVS_TILES_TIGHT: [n,4] = rectangle + 64-bit tile mask, written instead of rect; null = canonical*/);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
@@ -46,13 +47,15 @@ hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uin
 // A3: gathers the tile rectangles (4 x u16 per splat, written by A2) into depth order, offsets over their areas. Writes block offsets
 // and total_dev[0] = T; total_dev[1] is incremented when T exceeds `capacity` (instances the arenas can hold).
 size_t dvs_scan_scratch_words(int n);
+// tight != 0 (DVS_TILES_TIGHT): rect / rect_sorted are the 16-B records {rectangle, tile mask} of k_preprocess_fwd, a splat's count is the
+// number of set mask bits (an all-ones mask = the whole rectangle)
 hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect, uint32_t* rect_sorted,
-                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity);
+                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity, int tight);
 // A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order (streams ids + sorted rectangles).
 // n = n_views * n_per_view sorted elements whose values are global indices view * n_per_view + splat; tile ids are view * tiles_per_view + tile
 hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
                                 const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity,
-                                int n_per_view, int n_views, int tiles_per_view);
+                                int n_per_view, int n_views, int tiles_per_view, int tight);
 // A6: per-tile [start,end) from the sorted tile ids. T_dev (nullable): device-side count, T sizes the grid.
 hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles,
                                   const uint64_t* T_dev = nullptr, uint64_t T_expected = 0);

@@ -76,7 +76,8 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
                  int* __restrict__ radii, float4* __restrict__ splat2d /*[n] 64-B records, DVS_S2D_* */, float* __restrict__ depth,
                  uint32_t* __restrict__ flags,
                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                 uint2* __restrict__ rect /*tile rectangle [minx | maxx << 16, miny | maxy << 16]; empty for culled splats*/) {
+                 uint2* __restrict__ rect /*tile rectangle [minx | maxx << 16, miny | maxy << 16]; empty for culled splats*/,
+                 uint4* __restrict__ rect16 /*DVS_TILES_TIGHT: {rectangle, tile mask lo, hi} instead of `rect` (null: canonical rectangles)*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] when deg>0
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
@@ -109,6 +110,7 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     int out_radius = 0;
     uint32_t out_tiles = 0, out_flags = 0, out_key = 0xFFFFFFFFu;
     uint2 out_rect = make_uint2(0u, 0u);
+    unsigned long long out_mask = 0ull;
     float2 out_mean = make_float2(0.f, 0.f);
     float out_depth = 0.f;
     float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -231,6 +233,13 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
         out_flags = fl;
         out_tiles = (uint32_t)touched;
         out_rect = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
+        if (rect16) {          // DVS_TILES_TIGHT: only the tiles the alpha >= 1/255 ellipse reaches (rectangles of more than 64 tiles stay whole)
+            out_mask = ~0ull;
+            if (touched <= 64) {
+                out_mask = dvs_tight_tile_mask(out_co.x, out_co.y, out_co.z, opac, m2x, m2y, rminx, rminy, rmaxx, rmaxy);
+                out_tiles = (uint32_t)__popcll(out_mask);
+            }
+        }
     } while (0);
 
     radii[o] = out_radius;
@@ -267,7 +276,8 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     }
     flags[o] = out_flags;
     tiles_touched[o] = out_tiles;
-    rect[o] = out_rect;
+    if (rect16) rect16[o] = make_uint4(out_rect.x, out_rect.y, (uint32_t)out_mask, (uint32_t)(out_mask >> 32));
+    else rect[o] = out_rect;
     depth_key[o] = out_key;
     ids[o] = (uint32_t)o;
     }   // views
@@ -870,13 +880,13 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCams& cams, int n_views,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
                                      float* depth, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect) {
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect, uint32_t* rect16) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     if (shn_tiled) {
 #define DVS_A2(T, M, LDS) hipLaunchKernelGGL((k_preprocess_fwd<T, M>), dim3(grid), dim3(PP_BLOCK), LDS, st, cams, n_views, n, pos, sh0, shN, opacity, \
                                              scale, rot, deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,          \
-                                             tiles_touched, depth_key, ids, (uint2*)rect)
+                                             tiles_touched, depth_key, ids, (uint2*)rect, (uint4*)rect16)
         if (n_views > 1) DVS_A2(true, true, 0); else DVS_A2(true, false, 0);
     } else {
         const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;

@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sort
 // holding one block sit in one wave (BK = 64) or one half wave (BK = 32), so ranks and lengths come straight from that wave's ballots.
 template <int BK>
 __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const float4* __restrict__ splat2d, uint32_t id, int cnt, int base, int parity,
-                                         float tile_x0, float tile_y0) {
+                                         float tile_x0, float tile_y0, int dbg = 0) {
     constexpr int GPT = 16 * BK / RB;
     static_assert(GPT == 4 || GPT == 2, "BK must be 64 or 32");
     const int t = threadIdx.x, e = t % BK, sub = t / BK, lane = t & 63;
@@ -104,6 +104,8 @@ __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const float4* __restrict_
         const bool hin = y0 <= 0.f && y1 >= 0.f;
         const float ye = y0 > 0.f ? y0 : y1;
         const float hx = nb_a * ye, hbase = hin ? __builtin_inff() : ye * ye * det_a;
+        if (dbg & 16384) hits = 0xFu;                       // timing only (with dbg 8: no list loop): staging without the ellipse-vs-block tests
+        else
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const float x0 = ox + 4.f * (float)i, x1 = x0 + 3.f;
@@ -353,7 +355,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         const int base = b * BK;
         const int cnt = min(BK, (int)todo - base);
         // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
-        tr_stage<BK>(L, splat2d, id_stage, cnt, base, b & 1, tile_x0, tile_y0);
+        tr_stage<BK>(L, splat2d, id_stage, cnt, base, b & 1, tile_x0, tile_y0, dbg);
         if (!(dbg & 256)) __syncthreads();                  // batch staged; the tables are zero again        (dbg 256: timing of a barrier-free batch loop — wrong results)
 #if TR_PREFETCH
         float pf = 0.f;                                     // one dword of each record of batch b - 1: the line is in the cache when tr_stage asks for it

@@ -563,6 +563,8 @@ void GaussianTrainerScene::trainStep() {
     opts.sh_degree = deg; opts.antialias = m.cfg.mipAntiliased ? 1 : 0; opts.absgrad = absgrad ? 1 : 0; opts.accumulate = 0;
     opts.shn_layout = DVS_SHN_TILED;
     opts.grad_mode = DVS_GRAD_LINEAGE;          // the backward of the lineage the reference credits (README.md:95)
+    static const bool tight_tiles = [] { const char* e = getenv("DVS_TIGHT_TILES"); return e && e[0] == '1'; }();
+    opts.tile_bounds = tight_tiles ? DVS_TILES_TIGHT : DVS_TILES_CANONICAL;     // opt-in: same images and gradients, shorter tile lists (dvs_raster.h)
     const dvs_splats sp = m.splats();
     const size_t img = 3 * (size_t)m.W * m.H;
     const float w_ssim = m.d_ssim_maps[0] ? m.cfg.ssimWeight : 0.f;

@@ -131,12 +131,13 @@ class Rasterizer:
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
     # -- the two ops -------------------------------------------------------------------------
-    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False, grad_mode=0):
+    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False, grad_mode=0, tight_tiles=False):
         """params: dict of CUDA float32 tensors (A0 layout; params["shN"] in the tiled layout when shn_tiled).
         grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (dvs_raster.h) — used by the backward calls that follow.
+        tight_tiles: dvs_opts.tile_bounds = DVS_TILES_TIGHT (opt-in; the canonical 3-sigma rectangles are the default).
         Returns out_rgb [3,H,W] (CUDA)."""
         sp = self._splats(params, shn_tiled)
-        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled), int(grad_mode))
+        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled), int(grad_mode), int(bool(tight_tiles)))
         self._tiled = bool(shn_tiled)
         if out is None:
             out = torch.empty((3, cam.height, cam.width), dtype=torch.float32, device=self.tdev)
@@ -151,12 +152,12 @@ class Rasterizer:
         return out
 
     # -- multi-view batches (dvs_raster_forward_views / dvs_raster_backward_views) -----------------------------------
-    def forward_views(self, params, cams, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False, grad_mode=0):
+    def forward_views(self, params, cams, sh_degree=3, antialias=False, absgrad=False, out=None, shn_tiled=False, grad_mode=0, tight_tiles=False):
         """cams: list of Camera (same image size). Returns out_rgb [V,3,H,W] (CUDA). One depth sort / scan / (view, tile) sort /
         composite launch for the whole batch; the parameters are read once."""
         V = len(cams)
         sp = self._splats(params, shn_tiled)
-        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled), int(grad_mode))
+        opts = Opts(sh_degree, int(antialias), int(absgrad), 0, int(shn_tiled), int(grad_mode), int(bool(tight_tiles)))
         self._tiled = bool(shn_tiled)
         if out is None:
             out = torch.empty((V, 3, cams[0].height, cams[0].width), dtype=torch.float32, device=self.tdev)
@@ -218,7 +219,8 @@ class Rasterizer:
             # the tiled shN array has pad lanes (splats >= n of the last tile) that the kernels never write: keep them defined
             grads = {k: (torch.zeros_like(params[k]) if (k == "shN" and self._tiled) else torch.empty_like(params[k])) for k in PARAM_KEYS}
             accumulate = False
-        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout, self._opts.grad_mode)
+        opts = Opts(self._opts.sh_degree, self._opts.antialias, self._opts.absgrad, int(accumulate), self._opts.shn_layout, self._opts.grad_mode,
+                    self._opts.tile_bounds)
         if self._opts.absgrad and "absgrad2d" not in grads:
             grads["absgrad2d"] = torch.empty((n, 2), dtype=torch.float32, device=self.tdev)
         if want_mean2d and "mean2d" not in grads:

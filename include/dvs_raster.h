@@ -98,8 +98,22 @@ typedef struct dvs_opts {
     int32_t accumulate;    /* backward: 0 = overwrite gradient rows, 1 = add into them (multi-view batches) */
     int32_t shn_layout;    /* DVS_SHN_ROWS (default 0) or DVS_SHN_TILED */
     int32_t grad_mode;     /* DVS_GRAD_TRUE (default 0) or DVS_GRAD_LINEAGE: which backward the two non-smooth points of the forward get */
-    int32_t _reserved[2];
+    int32_t tile_bounds;   /* DVS_TILES_CANONICAL (default 0) or DVS_TILES_TIGHT: which (splat, tile) instances the binning stage emits */
+    int32_t _reserved[1];
 } dvs_opts;
+
+/* dvs_opts.tile_bounds.
+ *   DVS_TILES_CANONICAL  every tile of the ceil(3 sigma) rectangle of the splat (the rule of the rasterizer lineage the reference
+ *                        credits, README.md:95): tiles_touched, the (tile | depth) keys, the per-tile lists, n_contrib and
+ *                        num_rendered are the canonical ones every parity test pins. The default, and what the bench headline runs.
+ *   DVS_TILES_TIGHT      OPT-IN: of that rectangle, only the tiles the splat's alpha >= 1/255 ellipse can reach (the cull the in-tree
+ *                        viewer applies per pixel, gsplat_ps.hlsl:60-65; exact ellipse-vs-tile-rectangle test with a 1e-3 safety
+ *                        margin on alpha, evaluated in preprocess from IEEE-exact operations so that the CPU oracle reproduces the
+ *                        instance list bit for bit). Rectangles of more than 64 tiles are kept whole. Images, final_T and every
+ *                        gradient are those of the canonical lists (an instance that is dropped never contributes to a pixel);
+ *                        tiles_touched, num_rendered, the exported lists and n_contrib (a list position) refer to the shorter
+ *                        lists. At BASELINE config C3, 28 % of the canonical instances go. */
+enum { DVS_TILES_CANONICAL = 0, DVS_TILES_TIGHT = 1 };
 
 /* dvs_opts.grad_mode. The forward is identical in both modes; they differ only where the forward is not smooth:
  *   DVS_GRAD_TRUE    the exact derivative of the forward: a pixel whose alpha hit the 0.99 cap passes no gradient to the

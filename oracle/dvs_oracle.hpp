@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <vector>
 #include "../include/dvs_raster.h"
 
@@ -140,6 +141,66 @@ template <class T> inline void cov3d_from_scale_rot(const T s[3], const T R[9], 
     cov[5] = (M[6] * M[6] + M[7] * M[7]) + M[8] * M[8];
 }
 
+// deterministic ln(x), x > 0 normal: the CPU twin of dvs_log_det (divshot_amd/csrc/dvs_device.h), same operations in the same order
+inline float det_logf(float x) {
+    uint32_t bits; std::memcpy(&bits, &x, 4);
+    int e = (int)(bits >> 23) - 127;
+    uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float m; std::memcpy(&m, &mb, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float t2 = t * t;
+    float p = 0.111111111f;
+    p = std::fma(p, t2, 0.142857143f);
+    p = std::fma(p, t2, 0.2f);
+    p = std::fma(p, t2, 0.333333333f);
+    p = std::fma(p, t2, 1.0f);
+    return std::fma((float)e, 0.693147181f, (2.0f * t) * p);
+}
+template <class T> inline T det_log(T x);
+template <> inline float  det_log<float>(float x)   { return det_logf(x); }
+template <> inline double det_log<double>(double x) { return std::log(x); }
+
+// DVS_TILES_TIGHT (include/dvs_raster.h): the tiles of a splat's rectangle its alpha >= 1/255 ellipse can reach — the CPU twin of
+// dvs_tight_tile_mask (divshot_amd/csrc/dvs_device.h), the same IEEE operations in the same order, so that the fp32 instantiation
+// reproduces the HIP path's instance list bit for bit. Anchor of the rule: the viewer's per-pixel alpha cull, gsplat_ps.hlsl:60-65.
+template <class T> inline uint64_t tight_tile_mask(T a, T b, T c, T o, T mx, T my, int rminx, int rminy, int rmaxx, int rmaxy) {
+    const T ac = a * c;
+    const T det = std::fmax(T(0), std::fma(T(-2.4e-7f), ac, ac - b * b));
+    const T inv_c = T(1) / c, inv_a = T(1) / a;
+    const T det_c = det * inv_c, det_a = det * inv_a, nb_c = -b * inv_c, nb_a = -b * inv_a;
+    const T kappa = T(2) * (det_log<T>(o) + T(5.5422648f));
+    const T inf = std::numeric_limits<T>::infinity();
+    uint64_t mask = 0;
+    int t = 0;
+    for (int ty = rminy; ty < rmaxy; ++ty) {
+        const T y0 = T(ty * kTile) - my, y1 = y0 + T(kTile - 1);
+        const bool hin = y0 <= T(0) && y1 >= T(0);
+        const T ye = y0 > T(0) ? y0 : y1;
+        const T hx = nb_a * ye, hbase = (ye * ye) * det_a;
+        for (int tx = rminx; tx < rmaxx; ++tx, ++t) {
+            const T x0 = T(tx * kTile) - mx, x1 = x0 + T(kTile - 1);
+            const bool vin = x0 <= T(0) && x1 >= T(0);
+            T qmin = T(0);
+            if (!(vin && hin)) {
+                qmin = inf;
+                if (!vin) {
+                    const T xe = x0 > T(0) ? x0 : x1;
+                    const T vy = nb_c * xe;
+                    const T d = std::fmin(std::fmax(vy, y0), y1) - vy;
+                    qmin = (c * d) * d + (xe * xe) * det_c;
+                }
+                if (!hin) {
+                    const T d = std::fmin(std::fmax(hx, x0), x1) - hx;
+                    qmin = std::fmin(qmin, (a * d) * d + hbase);
+                }
+            }
+            if (!(qmin > kappa)) mask |= (1ull << t);
+        }
+    }
+    return mask;
+}
+
 // ---- state -------------------------------------------------------------------------------------
 template <class T> struct State {
     int n = 0, W = 0, H = 0, tiles_x = 0, tiles_y = 0;
@@ -152,6 +213,7 @@ template <class T> struct State {
     std::vector<T> mean2d, depth, conic_opacity, rgb;
     std::vector<uint32_t> flags, tiles_touched;
     std::vector<int32_t> rect;           // [n,4] minx,miny,maxx,maxy
+    std::vector<uint64_t> tile_mask;     // DVS_TILES_TIGHT: surviving tiles of the rectangle, row-major (all ones: the whole rectangle)
     std::vector<uint32_t> depth_bits;    // fp32 bit pattern of depth (0 for culled)
     // A3-A6
     std::vector<uint32_t> offsets;       // inclusive scan of tiles_touched
@@ -183,7 +245,7 @@ template <class T> void preprocess_forward(State<T>& S) {
     S.tiles_x = (W + kTile - 1) / kTile; S.tiles_y = (H + kTile - 1) / kTile;
     S.radii.assign(n, 0); S.mean2d.assign(2 * (size_t)n, T(0)); S.depth.assign(n, T(0));
     S.conic_opacity.assign(4 * (size_t)n, T(0)); S.rgb.assign(3 * (size_t)n, T(0));
-    S.flags.assign(n, 0); S.tiles_touched.assign(n, 0); S.rect.assign(4 * (size_t)n, 0);
+    S.flags.assign(n, 0); S.tiles_touched.assign(n, 0); S.rect.assign(4 * (size_t)n, 0); S.tile_mask.assign(n, ~0ull);
     S.depth_bits.assign(n, 0);
     const int deg = S.opts.sh_degree;
 #pragma omp parallel for schedule(static)
@@ -296,6 +358,10 @@ template <class T> void preprocess_forward(State<T>& S) {
         S.conic_opacity[4 * i + 3] = opac;
         S.flags[i] = fl;
         S.tiles_touched[i] = (uint32_t)touched;
+        if (S.opts.tile_bounds == DVS_TILES_TIGHT && touched <= 64) {      // opt-in: only the tiles the alpha >= 1/255 ellipse reaches
+            S.tile_mask[i] = tight_tile_mask<T>(c * det_inv, -b * det_inv, a * det_inv, opac, m2x, m2y, rminx, rminy, rmaxx, rmaxy);
+            S.tiles_touched[i] = (uint32_t)__builtin_popcountll(S.tile_mask[i]);
+        }
         S.rect[4 * i + 0] = rminx; S.rect[4 * i + 1] = rminy; S.rect[4 * i + 2] = rmaxx; S.rect[4 * i + 3] = rmaxy;
     }
 }
@@ -313,8 +379,11 @@ template <class T> void bin(State<T>& S) {
         if (S.radii[i] <= 0) continue;
         uint64_t off = (i == 0) ? 0 : S.offsets[i - 1];
         const int32_t* r = &S.rect[4 * (size_t)i];
+        const uint64_t mask = S.tile_mask[i];
+        int t = 0;
         for (int y = r[1]; y < r[3]; ++y)
-            for (int x = r[0]; x < r[2]; ++x) {
+            for (int x = r[0]; x < r[2]; ++x, ++t) {
+                if (mask != ~0ull && !((mask >> t) & 1ull)) continue;           // DVS_TILES_TIGHT: this tile is out of the ellipse's reach
                 const uint64_t tile = (uint64_t)y * S.tiles_x + x;
                 keys[off] = (tile << 32) | S.depth_bits[i];      // depth > 0: raw IEEE bits order correctly
                 vals[off] = (uint32_t)i;

@@ -74,11 +74,11 @@ class Oracle:
             self.lib.dvso_destroy(self.h)
             self.h = None
 
-    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, grad_mode=0):
+    def forward(self, params, cam, sh_degree=3, antialias=False, absgrad=False, grad_mode=0, tight_tiles=False):
         """params: dict of numpy arrays (A0 layout); cam: divshot_amd.Camera (ctypes struct, same layout as dvs_camera)."""
         arrs = [np.ascontiguousarray(params[k], dtype=self.dtype) for k in ("pos", "sh0", "shN", "opacity", "scale", "rot")]
         n = arrs[0].shape[0]
-        opts = (C.c_int32 * 8)(sh_degree, int(antialias), int(absgrad), 0, 0, int(grad_mode), 0, 0)     # dvs_opts
+        opts = (C.c_int32 * 8)(sh_degree, int(antialias), int(absgrad), 0, 0, int(grad_mode), int(bool(tight_tiles)), 0)     # dvs_opts
         # (grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE — only the backward differs)
         self.W, self.H = cam.width, cam.height
         rc = self.lib.dvso_forward(self.h, n, *[a.ctypes.data for a in arrs], C.addressof(cam), C.addressof(opts))

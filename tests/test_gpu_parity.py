@@ -851,4 +851,78 @@ def test_sort_onesweep_variant_is_bit_exact_too(gpu_device):
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
                         "test_sort_pairs or G2_2k_64_deg3 or C2_100k_800_deg3"], capture_output=True, text=True, timeout=900, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    # (the sort test, the two canonical pipeline configurations and the same two with DVS_TILES_TIGHT)
+    assert p.returncode == 0 and "5 passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["C1_10k_256_deg0", "G2_2k_64_deg3", "ragged_5k_250x130_deg2_aa", "dense_3k_96_big", "C2_100k_800_deg3",
+                                  "rnd3_65", "rnd7_3500", "rnd9_6000"])
+def test_tight_tiles_opt_in(rast, oracle_mod, name):
+    """dvs_opts.tile_bounds = DVS_TILES_TIGHT (opt-in): the instance list the binning stage emits equals the
+    oracle twin's BIT FOR BIT (tiles_touched, (tile | depth) keys, values, ranges), is a sub-list of the canonical one, and nothing
+    anybody can observe downstream changes: the image and final_T are bit-identical to the canonical run's, the gradients agree to
+    fp32 summation order, and n_contrib names the same splat per pixel."""
+    import torch
+    from divshot_amd.raster import params_to_device
+    full = [k for k in CONFIGS if k.startswith(name)]
+    assert full, name
+    n, W, H, deg, seed, soff, aa, bg = CONFIGS[full[0]]
+    spec, P, cam, tgt = scene(n, W, H, deg, seed, scale_offset=soff, bg=bg)
+    Pd = params_to_device(P, rast.tdev)
+    rast.set_backward_variant("tr")
+    img_c = rast.forward(Pd, cam, sh_degree=deg, antialias=aa, absgrad=True).clone()
+    sc, keys_c = rast.saved(), rast.sorted_keys()
+    dL = ((img_c - torch.from_numpy(tgt).to(rast.tdev)) / tgt[0].size).contiguous()
+    g_c = {k: v.clone() for k, v in rast.backward(dL).items()}
+    img_t = rast.forward(Pd, cam, sh_degree=deg, antialias=aa, absgrad=True, tight_tiles=True).clone()
+    stt, keys_t = rast.saved(), rast.sorted_keys()
+    g_t = {k: v.clone() for k, v in rast.backward(dL).items()}
+    torch.cuda.synchronize()
+    o = oracle_mod.Oracle(np.float32)
+    o.forward(P, cam, sh_degree=deg, antialias=aa, tight_tiles=True)
+    np.testing.assert_array_equal(stt["tiles_touched"], o.get("tiles_touched"))
+    np.testing.assert_array_equal(keys_t, o.get("keys"))
+    np.testing.assert_array_equal(stt["vals"], o.get("vals"))
+    np.testing.assert_array_equal(stt["ranges"], o.get("ranges"))
+    np.testing.assert_array_equal(stt["radii"], sc["radii"])                       # visibility (radius > 0) is not redefined
+    assert set(keys_t.tolist()) <= set(keys_c.tolist()) and keys_t.size <= keys_c.size
+    if n >= 2000 and soff < 1.0:
+        assert keys_t.size < 0.9 * keys_c.size, (keys_t.size, keys_c.size)         # the point of the option
+    assert torch.equal(img_t, img_c), "tight tiles changed the image"
+    assert np.array_equal(stt["final_T"].view(np.uint32), sc["final_T"].view(np.uint32))
+    # n_contrib is a position in the (shorter) list: it must name the same last contributor
+    def last_splat(s):
+        nc, out = s["n_contrib"], np.full(s["n_contrib"].shape, -1, np.int64)
+        tiles_x = (W + 15) // 16
+        ys, xs = np.nonzero(nc)
+        t = (ys // 16) * tiles_x + xs // 16
+        out[ys, xs] = s["vals"][s["ranges"][t, 0].astype(np.int64) + nc[ys, xs].astype(np.int64) - 1]
+        return out
+    assert np.array_equal(last_splat(stt), last_splat(sc))
+    for k in g_c:
+        a, b = g_t[k].double(), g_c[k].double()
+        assert float((a - b).norm() / max(float(b.norm()), 1e-300)) < 2e-6, k
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, k
+
+
+def test_tight_tiles_multi_view_batch(gpu_device):
+    """The opt-in through the multi-view pass: every view's image bit-identical to the canonical batch, fewer instances, same gradients."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H, deg = 30_000, 320, 240, 2
+    spec = dv.make_spec(n, W, H, sh_degree=deg, n_cams=3, seed=9)
+    Pd = params_to_device(dv.synth_splats(spec), gpu_device)
+    cams = [dv.synth_camera(spec, i) for i in range(3)]
+    r = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=3)
+    img_c = r.forward_views(Pd, cams, sh_degree=deg, absgrad=True).clone()
+    Tc = r.get_num_rendered() if r.num_rendered == 2 ** 64 - 1 else r.num_rendered
+    dL = torch.randn_like(img_c) / (W * H)
+    g_c = {k: v.clone() for k, v in r.backward_views(dL).items()}
+    img_t = r.forward_views(Pd, cams, sh_degree=deg, absgrad=True, tight_tiles=True).clone()
+    Tt = r.get_num_rendered() if r.num_rendered == 2 ** 64 - 1 else r.num_rendered
+    g_t = r.backward_views(dL)
+    torch.cuda.synchronize()
+    assert torch.equal(img_t, img_c) and Tt < 0.9 * Tc, (Tt, Tc)
+    for k in g_c:
+        assert float((g_t[k].double() - g_c[k].double()).norm() / max(float(g_c[k].double().norm()), 1e-300)) < 2e-6, k
+    r.close()
