@@ -682,8 +682,19 @@ def main():
                     bytes_ = None                              # SURVEY's formula prices the sort as a whole: see "sort_total"
                 ent = {"stage": stg, "kernels": kern_names[stg], "ms_per_launch_set": ms_, "views_per_launch": G,
                        "algorithmic_bytes": bytes_ * G if bytes_ else None}
-                if bytes_:
-                    ent["achieved_GBps"] = bytes_ * G / (ms_ * 1e-3) / 1e9
+                launch_bytes = bytes_ * G if bytes_ else None
+                if stg in ("preprocess_fwd", "preprocess_bwd") and G > 1:
+                    # the multi-view pass reads the 236 B/splat of parameters ONCE for its G views: pricing it at G x the per-view formula
+                    # would put it above the HBM peak. Bytes the launch has to move: parameters once + the per-(view, splat) arrays.
+                    B_sh_ = 12 * (deg + 1) ** 2
+                    if stg == "preprocess_fwd":
+                        launch_bytes = (44 + B_sh_) * n + 112 * n * G                       # + 64-B record, radii / depth / flags / rect / key / id per (view, splat)
+                    else:
+                        launch_bytes = (48 + 12 + 12) * n * G + (44 + B_sh_) * n + 44 * n + 12 * n + B_sh_ * n   # rows in, dcolor out + in; params; geometry + SH gradients out
+                    ent["algorithmic_bytes_note"] = "per-launch bytes of the multi-view pass (parameters once); SURVEY's per-view figure x views is in algorithmic_bytes"
+                    ent["launch_bytes"] = launch_bytes
+                if launch_bytes:
+                    ent["achieved_GBps"] = launch_bytes / (ms_ * 1e-3) / 1e9
                     ent["frac_of_hbm_peak"] = ent["achieved_GBps"] / HBM_PEAK_GBPS
                 klist.append(ent)
             if sort_ms > 0:

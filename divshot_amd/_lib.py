@@ -94,6 +94,7 @@ _PROTOS = {
     "dvs_set_async": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_get_num_rendered": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "dvs_set_backward_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "dvs_debug_record_decisions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "dvs_set_forward_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_set_live_lists": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),

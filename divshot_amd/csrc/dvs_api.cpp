@@ -83,6 +83,7 @@ struct dvs_ctx {
     uint64_t* total_host = nullptr;      // pinned copy of both words (async: refreshed by every forward, read by the next one)
     uint64_t inst_cap = 0;               // instances the instance arenas can hold
     bool async_T = false;                // dvs_set_async: no host synchronisation inside dvs_raster_forward
+    uint64_t* rec_masks = nullptr; uint64_t rec_cap = 0;      // dvs_debug_record_decisions
     uint64_t overflow_seen = 0;          // value of total_host[1] already reported
     uint64_t lookback_seen = 0;          // value of total_host[2] already reported (DVS_SORT_ONESWEEP only)
     dvs_fwd_state st{};
@@ -321,6 +322,11 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
     // the live lists of A7 (entries that reach their tile, compacted) go into the sort's other pair of instance arrays, free by now
     c->live_splat = nullptr; c->live_pos = nullptr;
+    uint64_t* rec_masks = nullptr; uint64_t rec_cap = 0;          // dvs_debug_record_decisions (parity tests): one view, synchronous T
+    if (c->rec_masks && V == 1 && !c->async_T && (c->fwd_variant == DVS_FWD_QUADRANT)) {
+        rec_masks = c->rec_masks; rec_cap = c->rec_cap;
+        HIPCHECK(hipMemsetAsync(rec_masks, 0, (size_t)(T < rec_cap ? T : rec_cap) * 32, st));
+    }
     if (c->fwd_variant == DVS_FWD_QUADRANT || V > 1) {
         // Only the "tr" composite backward walks them (the other variants ignore them), and they cost the forward two 4-B stores per
         // instance: none for an inference-only context (dvs_set_live_lists(ctx, 0)) or another backward. The spare pair of the tile
@@ -329,7 +335,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         if (c->live_lists && c->bwd_variant == DVS_BWD_TR) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
         HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                        c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>(),
-                                       c->live_splat, c->live_pos));
+                                       c->live_splat, c->live_pos, rec_masks, rec_cap));
     } else
         HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
                                               c->splat2d.as<float>(), cam->bg, out_rgb,
@@ -662,6 +668,12 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
                        "invalid. The arena has been enlarged — repeat that view.";
         return DVS_ERR_CAPACITY;
     }
+    return DVS_OK;
+}
+
+int dvs_debug_record_decisions(dvs_ctx* c, uint64_t* take_masks, uint64_t capacity_instances) {
+    if (!c || (take_masks && (((uintptr_t)take_masks & 7u) || capacity_instances == 0))) { g_last_error = "dvs_debug_record_decisions: bad argument"; return DVS_ERR_INVALID; }
+    c->rec_masks = take_masks; c->rec_cap = take_masks ? capacity_instances : 0;
     return DVS_OK;
 }
 

@@ -68,7 +68,9 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
                                  uint32_t* n_contrib, uint32_t* live_splat /*[T] out (or null): per tile, the entries whose alpha >= 1/255 ellipse
                                  reaches the tile, compacted in list order from ranges[tile].x*/, uint32_t* live_pos /*[T] out (or null): list
-                                 position -> number of such entries before it in its tile*/);
+                                 position -> number of such entries before it in its tile*/,
+                                 uint64_t* take_masks /*test hook (or null): [take_cap][4] zeroed by the caller — per list position and 8x8 quadrant, the pixels that took the entry*/,
+                                 uint64_t take_cap);
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad, int grad_mode,

@@ -127,6 +127,10 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
                             // 5.216 -> 5.190 ms, +0.5 % views/s; bit-identical images); 0 = the round-3 form with scalar mask arithmetic
 #endif
 // ---- A7 -------------------------------------------------------------------------------------------
+// RECORD (dvs_debug_record_decisions, parity tests only): additionally stores, per (list position, 8x8 quadrant), the 64-bit mask of the
+// pixels that TOOK the entry — the kernel's own threshold decisions — so that the fp64 oracle can be run on exactly these decisions
+// (tests/test_gpu_parity.py: no "tainted" carve-out). Same arithmetic, same images.
+template <bool RECORD>
 __global__ void __launch_bounds__(RB)
 k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
              int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
@@ -134,7 +138,8 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
              float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
              uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
              uint32_t* __restrict__ live_pos /*[T] per list position: how many entries before it (in its tile) reach the tile*/,
-             int dbg_arg /*experiment builds: 1 = stage the batches but skip the walk (timing only)*/) {
+             int dbg_arg /*experiment builds: 1 = stage the batches but skip the walk (timing only)*/,
+             uint64_t* __restrict__ take_masks /*RECORD: [capacity][4], zeroed by the caller*/, uint64_t take_cap) {
     __shared__ FwdLds L;
     (void)bg_arg;
     const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;
@@ -210,6 +215,7 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
                 const float alpha = fminf(DVS_ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(p2));
                 const float aT = alpha * T;
                 const float test_T = T - aT;                       // = T (1 - alpha)
+                const uint64_t nd_before = notdone;
 #if FWD_CMPX
                 // The predicates as a v_cmpx chain: EXEC = notdone, narrowed by the two alpha-rule compares to the pixels the splat can
                 // contribute to; the stop test runs under that mask (VCC = pixels that stop here, WITHOUT this splat), leaves `notdone`
@@ -250,6 +256,12 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
                              : [tk] "s"(m_take), [cr] "v"(B.z), [cg] "v"(B.w), [cbl] "v"(cb), [at] "v"(aT), [idx] "s"(idx)
                              : "scc");                                  // (s_and_saveexec writes SCC)
 #endif
+                if (RECORD) {       // the same three comparisons on the same registers as the predicates above
+                    const uint64_t took = nd_before & __builtin_amdgcn_ballot_w64(!(p2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < DVS_ALPHA_MIN)) &
+                                          ~__builtin_amdgcn_ballot_w64(test_T < DVS_T_STOP);
+                    const uint64_t pos = (uint64_t)range.x + (uint64_t)(idx - 1u);
+                    if (lane == 0 && pos < take_cap) take_masks[pos * 4 + wave] = took;
+                }
             }
         }
     }
@@ -604,13 +616,17 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
-                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos) {
+                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos, uint64_t* take_masks, uint64_t take_cap) {
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     static const int dbg = dvs_experiment_int("DVS_FWD_DEBUG");
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                       (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, dbg);
+    if (take_masks)
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
+                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, dbg, take_masks, take_cap);
+    else
+        hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
+                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, dbg, nullptr, 0);
     return hipGetLastError();
 }
 

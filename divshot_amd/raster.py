@@ -111,6 +111,17 @@ class Rasterizer:
         """dvs_set_live_lists: the forward's compacted per-tile lists for the "tr" backward (default on)."""
         check(lib.dvs_set_live_lists(self.ctx, 1 if on else 0), "dvs_set_live_lists")
 
+    def record_decisions(self, capacity_instances):
+        """dvs_debug_record_decisions (test hook): single-view synchronous forwards from now on record which pixel took which list entry;
+        returns the device tensor [capacity, 4] (uint64 as int64) they are written to. capacity 0 / None switches it off."""
+        if not capacity_instances:
+            check(lib.dvs_debug_record_decisions(self.ctx, None, 0), "dvs_debug_record_decisions")
+            self._rec = None
+            return None
+        self._rec = torch.zeros((int(capacity_instances), 4), dtype=torch.int64, device=self.tdev)
+        check(lib.dvs_debug_record_decisions(self.ctx, self._rec.data_ptr(), int(capacity_instances)), "dvs_debug_record_decisions")
+        return self._rec
+
     def enable_timing(self, on=True):
         check(lib.dvs_enable_stage_timing(self.ctx, 1 if on else 0))
 

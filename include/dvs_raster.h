@@ -253,6 +253,14 @@ int dvs_get_view_state(dvs_ctx* ctx, int view, dvs_fwd_state* state);
 int dvs_set_async(dvs_ctx* ctx, int enable);
 int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
 
+/* TEST HOOK of the parity suite. While take_masks is non-NULL, every single-view synchronous forward on the context (default A7 kernel)
+ * also records ITS OWN threshold decisions: take_masks[4 * j + q] (device memory, 8-byte aligned, capacity_instances * 4 words, zeroed by
+ * the forward) = 64-bit mask of the pixels of 8x8 quadrant q of the tile that took list entry j (alpha >= 1/255, power <= 0, not yet
+ * saturated). The fp64 oracle replays exactly these decisions (oracle dvso_set_replay), which removes the only legitimate source of
+ * disagreement between an fp32 and an fp64 rasterizer — a threshold passed on one side and missed on the other — so that EVERY splat
+ * is held to the 1e-4 bar (tests/test_gpu_parity.py). Same arithmetic and images as without it; NULL switches it off. */
+int dvs_debug_record_decisions(dvs_ctx* ctx, uint64_t* take_masks, uint64_t capacity_instances);
+
 /* The composite kernels exist in several variants with the same inputs and outputs, kept selectable so that the measured
  * comparison can be repeated (all of them pass the same parity tests). Backward (A8), results equal to fp32 roundoff:
  *   3 "tr"      (default since round 3) per-4x4-pixel-block splat lists; a list step ends when the pair's two per-pixel scalars

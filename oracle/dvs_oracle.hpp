@@ -213,6 +213,8 @@ template <class T> struct State {
     std::vector<T> mean2d, depth, conic_opacity, rgb;
     std::vector<uint32_t> flags, tiles_touched;
     std::vector<int32_t> rect;           // [n,4] minx,miny,maxx,maxy
+    std::vector<uint64_t> replay;        // decision replay (tests): [T][4] — bit l of word q of list position j = pixel lane l of 8x8 quadrant q of
+                                         // the tile takes that entry (as the HIP forward decided: dvs_debug_record_decisions); empty = own decisions
     std::vector<uint64_t> tile_mask;     // DVS_TILES_TIGHT: surviving tiles of the rectangle, row-major (all ones: the whole rectangle)
     std::vector<uint32_t> depth_bits;    // fp32 bit pattern of depth (0 for culled)
     // A3-A6
@@ -224,6 +226,7 @@ template <class T> struct State {
     std::vector<T> out_color, final_T;   // [3,H,W], [H,W]
     std::vector<uint32_t> n_contrib;
     std::vector<uint8_t> fragile;        // [H,W] a threshold decision at this pixel had < 1e-5 relative margin
+    std::vector<uint8_t> cap_fragile;    // [H,W] an alpha at this pixel lies within 1e-5 (relative) of the 0.99 cap (a decision of the DVS_GRAD_TRUE backward)
     // A8
     std::vector<T> dL_dmean2d, dL_dconic_opacity, dL_drgb, absgrad;   // [n,2],[n,4],[n,3],[n,2]
     // A9
@@ -411,7 +414,7 @@ template <class T> inline bool near_rel(T v, T thr) { return std::fabs(v - thr) 
 template <class T> void render_forward(State<T>& S) {
     const int W = S.W, H = S.H;
     const size_t P = (size_t)W * H;
-    S.out_color.assign(3 * P, T(0)); S.final_T.assign(P, T(1)); S.n_contrib.assign(P, 0); S.fragile.assign(P, 0);
+    S.out_color.assign(3 * P, T(0)); S.final_T.assign(P, T(1)); S.n_contrib.assign(P, 0); S.fragile.assign(P, 0); S.cap_fragile.assign(P, 0);
     uint64_t inter = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : inter)
     for (int tile = 0; tile < S.tiles_x * S.tiles_y; ++tile) {
@@ -425,27 +428,31 @@ template <class T> void render_forward(State<T>& S) {
                 T Tr = T(1), C0 = T(0), C1 = T(0), C2 = T(0);
                 uint32_t contributor = 0, last = 0;
                 uint8_t frag = 0;
+                const bool rp = !S.replay.empty();                    // decisions given (k_render_fwd's): no threshold is evaluated here
+                const int rq = (ly >> 3) * 2 + (lx >> 3), rl = (ly & 7) * 8 + (lx & 7);
                 for (uint32_t j = beg; j < end; ++j) {
                     ++contributor; ++inter;
+                    if (rp && !((S.replay[4 * (size_t)j + rq] >> rl) & 1ull)) continue;
                     const uint32_t id = S.vals[j];
                     const T dx = S.mean2d[2 * id] - pxf, dy = S.mean2d[2 * id + 1] - pyf;
                     const T* co = &S.conic_opacity[4 * (size_t)id];
                     const T power = T(-0.5f) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > T(0)) continue;
+                    if (!rp && power > T(0)) continue;
                     const T oa = co[3] * det_exp<T>(power);
                     const T alpha = std::fmin(T(kAlphaMax), oa);
                     if (near_rel<T>(oa, T(kAlphaMin))) frag = 1;
-                    if (alpha < T(kAlphaMin)) continue;
+                    if (near_rel<T>(oa, T(kAlphaMax))) frag |= 2;         // (bit 1: the 0.99 cap — a decision of the DVS_GRAD_TRUE backward)
+                    if (!rp && alpha < T(kAlphaMin)) continue;
                     const T test_T = Tr * (T(1) - alpha);
-                    if (near_rel<T>(test_T, T(kTStop))) frag = 1;
-                    if (test_T < T(kTStop)) break;
+                    if (near_rel<T>(test_T, T(kTStop))) frag |= 1;
+                    if (!rp && test_T < T(kTStop)) break;
                     const T w = alpha * Tr;
                     C0 = C0 + S.rgb[3 * id] * w; C1 = C1 + S.rgb[3 * id + 1] * w; C2 = C2 + S.rgb[3 * id + 2] * w;
                     Tr = test_T;
                     last = contributor;
                 }
                 const size_t pix = (size_t)y * W + x;
-                S.final_T[pix] = Tr; S.n_contrib[pix] = last; S.fragile[pix] = frag;
+                S.final_T[pix] = Tr; S.n_contrib[pix] = last; S.fragile[pix] = frag & 1; S.cap_fragile[pix] = (frag >> 1) & 1;
                 S.out_color[0 * P + pix] = C0 + Tr * T(S.cam.bg[0]);
                 S.out_color[1 * P + pix] = C1 + Tr * T(S.cam.bg[1]);
                 S.out_color[2 * P + pix] = C2 + Tr * T(S.cam.bg[2]);
@@ -481,18 +488,21 @@ template <class T> void render_backward(State<T>& S, const T* dL_dout /*[3,H,W]*
                 const T dLp[3] = {dL_dout[pix], dL_dout[P + pix], dL_dout[2 * P + pix]};
                 const T bg_dot = (T(S.cam.bg[0]) * dLp[0] + T(S.cam.bg[1]) * dLp[1]) + T(S.cam.bg[2]) * dLp[2];
                 T accum[3] = {T(0), T(0), T(0)}, last_alpha = T(0), last_col[3] = {T(0), T(0), T(0)};
+                const bool rp = !S.replay.empty();
+                const int rq = (ly >> 3) * 2 + (lx >> 3), rl = (ly & 7) * 8 + (lx & 7);
                 for (uint32_t k = last; k-- > 0;) {          // contributor index k+1, list position beg+k
                     const uint32_t j = beg + k;
                     (void)end;
+                    if (rp && !((S.replay[4 * (size_t)j + rq] >> rl) & 1ull)) continue;
                     const uint32_t id = S.vals[j];
                     const T dx = S.mean2d[2 * id] - pxf, dy = S.mean2d[2 * id + 1] - pyf;
                     const T* co = &S.conic_opacity[4 * (size_t)id];
                     const T power = T(-0.5f) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > T(0)) continue;
+                    if (!rp && power > T(0)) continue;
                     const T G = det_exp<T>(power);
                     const T oa = co[3] * G;
                     const T alpha = std::fmin(T(kAlphaMax), oa);
-                    if (alpha < T(kAlphaMin)) continue;
+                    if (!rp && alpha < T(kAlphaMin)) continue;
                     Tr = Tr / (T(1) - alpha);
                     const T dchannel_dcolor = alpha * Tr;
                     T dL_dalpha = T(0);

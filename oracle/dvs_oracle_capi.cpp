@@ -29,7 +29,7 @@ const void* get_array(dvso::State<T>& S, const std::string& name, uint64_t* coun
     DVSO_ARR("tiles_touched", S.tiles_touched) DVSO_ARR("rect", S.rect) DVSO_ARR("depth_bits", S.depth_bits)
     DVSO_ARR("offsets", S.offsets) DVSO_ARR("keys", S.keys) DVSO_ARR("vals", S.vals) DVSO_ARR("ranges", S.ranges)
     DVSO_ARR("out_color", S.out_color) DVSO_ARR("final_T", S.final_T) DVSO_ARR("n_contrib", S.n_contrib)
-    DVSO_ARR("fragile", S.fragile)
+    DVSO_ARR("fragile", S.fragile) DVSO_ARR("cap_fragile", S.cap_fragile)
     DVSO_ARR("dL_dmean2d", S.dL_dmean2d) DVSO_ARR("dL_dconic_opacity", S.dL_dconic_opacity)
     DVSO_ARR("dL_drgb", S.dL_drgb) DVSO_ARR("absgrad", S.absgrad)
     DVSO_ARR("g_pos", S.g_pos) DVSO_ARR("g_sh0", S.g_sh0) DVSO_ARR("g_shN", S.g_shN)
@@ -59,11 +59,24 @@ int dvso_forward(void* hp, int n, const void* pos, const void* sh0, const void* 
     Handle* h = (Handle*)hp;
     if (h->is_double) {
         load_inputs(h->d, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
-        dvso::preprocess_forward(h->d); dvso::bin(h->d); dvso::render_forward(h->d);
+        dvso::preprocess_forward(h->d); dvso::bin(h->d);
+        if (!h->d.replay.empty() && h->d.replay.size() != 4 * h->d.vals.size()) return 2;     // the recorded lists are not this scene's
+        dvso::render_forward(h->d);
     } else {
         load_inputs(h->f, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
-        dvso::preprocess_forward(h->f); dvso::bin(h->f); dvso::render_forward(h->f);
+        dvso::preprocess_forward(h->f); dvso::bin(h->f);
+        if (!h->f.replay.empty() && h->f.replay.size() != 4 * h->f.vals.size()) return 2;
+        dvso::render_forward(h->f);
     }
+    return 0;
+}
+
+// Decision replay (parity tests): from now on render_forward / render_backward take the per-(list position, 8x8 quadrant) 64-bit masks
+// of WHICH pixel takes WHICH entry instead of evaluating the thresholds — the masks the HIP forward recorded
+// (dvs_debug_record_decisions). count = 4 * number of instances (0 clears). Returns 0.
+int dvso_set_replay(void* hp, const uint64_t* masks, uint64_t count) {
+    Handle* h = (Handle*)hp;
+    h->f.replay.assign(masks, masks + count); h->d.replay.assign(masks, masks + count);
     return 0;
 }
 

@@ -33,6 +33,8 @@ def _load():
         _lib.dvso_backward.restype = C.c_int
         _lib.dvso_backward.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dvso_set_grad_mode.argtypes = [C.c_void_p, C.c_int]
+        _lib.dvso_set_replay.restype = C.c_int
+        _lib.dvso_set_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         _lib.dvso_array.restype = C.c_void_p
         _lib.dvso_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib.dvso_interactions.restype = C.c_uint64
@@ -48,7 +50,7 @@ def _load():
 
 _INT_DTYPES = {"radii": np.int32, "rect": np.int32, "flags": np.uint32, "tiles_touched": np.uint32,
                "depth_bits": np.uint32, "offsets": np.uint32, "keys": np.uint64, "vals": np.uint32,
-               "ranges": np.uint32, "n_contrib": np.uint32, "fragile": np.uint8}
+               "ranges": np.uint32, "n_contrib": np.uint32, "fragile": np.uint8, "cap_fragile": np.uint8}
 _SHAPES = {"mean2d": (-1, 2), "conic_opacity": (-1, 4), "rgb": (-1, 3), "rect": (-1, 4), "ranges": (-1, 2),
            "dL_dmean2d": (-1, 2), "dL_dconic_opacity": (-1, 4), "dL_drgb": (-1, 3), "absgrad": (-1, 2),
            "g_pos": (-1, 3), "g_sh0": (-1, 3), "g_shN": (-1, 15, 3), "g_scale": (-1, 3), "g_rot": (-1, 4)}
@@ -82,8 +84,15 @@ class Oracle:
         # (grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE — only the backward differs)
         self.W, self.H = cam.width, cam.height
         rc = self.lib.dvso_forward(self.h, n, *[a.ctypes.data for a in arrs], C.addressof(cam), C.addressof(opts))
-        assert rc == 0
+        assert rc == 0, "the recorded decisions do not belong to these tile lists" if rc == 2 else rc
         return self.get("out_color").reshape(3, self.H, self.W)
+
+    def set_replay(self, masks):
+        """Decision replay: masks = uint64 [T, 4] recorded by the HIP forward (Rasterizer.record_decisions) — bit l of masks[j, q] says pixel
+        lane l of 8x8 quadrant q of the tile takes list entry j. From now on forward / backward use these decisions instead of evaluating
+        the alpha / transmittance thresholds (None or an empty array: back to the oracle's own decisions)."""
+        m = np.ascontiguousarray(masks if masks is not None else np.zeros((0, 4)), dtype=np.uint64)
+        assert self.lib.dvso_set_replay(self.h, m.ctypes.data, m.size) == 0
 
     def backward(self, dL_dout, grad_mode=None):
         """grad_mode: None = the mode given to forward(); 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (the forward does not depend on it)."""
@@ -106,7 +115,7 @@ class Oracle:
             a = np.empty((0,), dt)
         else:
             a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_byte)), shape=(cnt.value * eb.value,)).view(dt).copy()
-        if name in ("final_T", "n_contrib", "fragile"):
+        if name in ("final_T", "n_contrib", "fragile", "cap_fragile"):
             return a.reshape(self.H, self.W)
         if name in _SHAPES:
             return a.reshape(_SHAPES[name])

@@ -136,22 +136,44 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     m, worst = rel_close(saved["final_T"][ok], o.get("final_T")[ok], 1e-4, 1e-6)
     assert m.all(), f"final_T worst {worst}"
 
-    # --- A8/A9 backward vs fp64 oracle driven by the SAME upstream gradient -------------------------------
-    # A threshold decision (alpha < 1/255, T < 1e-4) that falls within rounding distance of its threshold can
-    # go differently in fp32 and fp64; every splat whose footprint holds such a "fragile" pixel is "tainted"
-    # and is compared with the fp32 oracle (same decisions as the GPU) instead of the fp64 one.
+    # --- decision replay (round 4) -------------------------------------------------------------------------------------------
+    # A threshold decision (alpha < 1/255, T (1 - alpha) < 1e-4, power > 0) that falls within rounding distance of its threshold can go
+    # differently in fp32 and fp64. Rounds 1-3 carved the affected ("tainted") splats out of the strict comparison; now the HIP forward
+    # RECORDS its decisions (dvs_debug_record_decisions: per list entry and 8x8 quadrant, the pixels that took the entry) and the fp64
+    # oracle replays exactly those, so every pixel and every splat is held to the strict bar. What is left outside: splats that reach a
+    # pixel whose alpha sits within 1e-5 of the 0.99 cap (a decision of the DVS_GRAD_TRUE backward that the forward does not take).
+    Tn = int(rast.num_rendered)
+    rec = rast.record_decisions(max(Tn, 1))
+    from divshot_amd.raster import params_to_device as _p2d
+    img_again = rast.forward(_p2d(P, rast.tdev), cam, sh_degree=deg, antialias=aa, absgrad=True)
+    import torch as _torch
+    _torch.cuda.synchronize()
+    assert np.array_equal(img_again.cpu().numpy().view(np.uint32), img.view(np.uint32)), "recording the decisions changed the image"
+    masks = rec[:Tn].cpu().numpy().view(np.uint64)
+    rast.record_decisions(0)
     o64 = oracle_mod.Oracle(np.float64)
     o64.forward(P, cam, sh_degree=deg, antialias=aa)
+    same_lists = np.array_equal(o64.get("vals"), o.get("vals")) and np.array_equal(o64.get("ranges"), o.get("ranges"))
+    # (fp64 can bin differently when a radius sits on an integer boundary: the fp32 oracle — same lists as the HIP path — replays then)
+    orp = oracle_mod.Oracle(np.float64 if same_lists else np.float32)
+    orp.set_replay(masks)
+    img_r = orp.forward(P, cam, sh_degree=deg, antialias=aa)
+    assert np.array_equal(orp.get("n_contrib"), saved["n_contrib"]), "replayed decisions do not reproduce n_contrib"
+    # EVERY pixel now, fragile or not, against fp64: 1e-4 relative; the absolute floor is 2e-6 of the image maximum (against the fp32
+    # oracle above it is 1e-6: a pixel with hundreds of contributors carries that much plain fp32 summation error; measured worst over
+    # the configurations: 1.05e-6)
+    m, worst = rel_close(img, img_r, 1e-4, 2e-6)
+    assert m.all(), f"rgb (replay, all pixels) worst {worst}"
+    m, worst = rel_close(saved["final_T"], orp.get("final_T"), 1e-4, 2e-6)
+    assert m.all(), f"final_T (replay, all pixels) worst {worst}"
     frag_any = frag | o64.get("fragile").astype(bool)
+    capf = orp.get("cap_fragile").astype(bool)
     tainted = np.zeros(n, bool)
-    fy, fx = np.where(frag_any)
+    fy, fx = np.where(capf)
     m2, rad, co = saved["mean2d"].astype(np.float64), saved["radii"], saved["conic_opacity"].astype(np.float64)
     tiles_x = (W + 15) // 16
     vals_l, ranges_l = saved["vals"], saved["ranges"].astype(np.int64)
     for x, y in zip(fx, fy):
-        # a flipped decision at (x, y) moves the gradient of every splat that can contribute there (alpha >= 1/255 up to the
-        # fragility margin) — not of splats whose 3-sigma box merely covers the pixel. Candidates: the pixel's tile list (a splat
-        # that reaches the pixel is binned into its tile).
         t_ = (y // 16) * tiles_x + x // 16
         cand = np.unique(vals_l[ranges_l[t_, 0]:ranges_l[t_, 1]])
         ddx, ddy = m2[cand, 0] - x, m2[cand, 1] - y
@@ -159,14 +181,12 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
         alpha = np.minimum(0.99, co[cand, 3] * np.exp(np.minimum(power, 0.0)))
         hit = (np.abs(ddx) <= rad[cand]) & (np.abs(ddy) <= rad[cand]) & (rad[cand] > 0) & (power <= 1e-6) & (alpha >= (1.0 / 255.0) * (1 - 1e-3))
         tainted[cand[hit]] = True
-    # the tainted set is the carve-out of this test: bounded for every config and written to the report
-    if not name.startswith(("dense", "rnd")):      # huge splats: one fragile pixel taints everything that covers it
-        assert tainted.mean() < 0.10, tainted.mean()
-    else:
-        assert tainted.mean() < 0.65, tainted.mean()
+    # what the replay cannot pin is bounded for EVERY configuration (no configuration looser than 1e-4 on > 10 %)
+    assert tainted.mean() < 0.10, tainted.mean()
     clean = ~tainted
     report = {"config": name, "n": n, "visible": int((saved["radii"] > 0).sum()), "T": int(rast.num_rendered),
-              "fragile_pixel_fraction": float(frag_any.mean()), "tainted_splat_fraction": float(tainted.mean()), "runs": {}}
+              "fragile_pixel_fraction": float(frag_any.mean()), "tainted_splat_fraction": float(tainted.mean()),
+              "decision_replay": "fp64" if same_lists else "fp32 (fp64 bins differently)", "cap_fragile_pixel_fraction": float(capf.mean()), "runs": {}}
 
     # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
     # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-3 relative L2
@@ -197,13 +217,12 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     culled = saved["radii"] == 0
     oracle_grads = {}
     for mode in (0, 1):
-        ref64 = {k: v.copy() for k, v in o64.backward(dL, grad_mode=mode).items()}
-        inter64 = {k: o64.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
+        # strict reference: the replaying oracle (the HIP path's own decisions); the plain fp32 oracle stays the reference of the few
+        # cap-tainted splats
+        ref64 = {k: v.copy() for k, v in orp.backward(dL, grad_mode=mode).items()}
+        inter64 = {k: orp.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
         ref32 = {k: v.copy() for k, v in o.backward(dL, grad_mode=mode).items()}
         inter32 = {k: o.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
-        if not np.array_equal(o64.get("n_contrib")[~frag_any], nc_ref[~frag_any]) or not np.array_equal(o64.get("vals"), o.get("vals")):
-            # fp64 binned differently somewhere (a radius at an integer boundary): the fp32 oracle is the strict reference
-            ref64, inter64 = ref32, inter32
         oracle_grads[mode] = ref64
         for variant in variants:
             grads, inter = runs[(mode, variant)]
