@@ -213,6 +213,8 @@ template <class T> struct State {
     std::vector<T> mean2d, depth, conic_opacity, rgb;
     std::vector<uint32_t> flags, tiles_touched;
     std::vector<int32_t> rect;           // [n,4] minx,miny,maxx,maxy
+    std::vector<uint64_t> take_masks;    // [T][4]: the decisions THIS forward took, in the layout dvs_debug_record_decisions uses (when record_masks is set)
+    bool record_masks = false;
     std::vector<uint64_t> replay;        // decision replay (tests): [T][4] — bit l of word q of list position j = pixel lane l of 8x8 quadrant q of
                                          // the tile takes that entry (as the HIP forward decided: dvs_debug_record_decisions); empty = own decisions
     std::vector<uint64_t> tile_mask;     // DVS_TILES_TIGHT: surviving tiles of the rectangle, row-major (all ones: the whole rectangle)
@@ -415,6 +417,7 @@ template <class T> void render_forward(State<T>& S) {
     const int W = S.W, H = S.H;
     const size_t P = (size_t)W * H;
     S.out_color.assign(3 * P, T(0)); S.final_T.assign(P, T(1)); S.n_contrib.assign(P, 0); S.fragile.assign(P, 0); S.cap_fragile.assign(P, 0);
+    S.take_masks.assign(S.record_masks ? 4 * S.vals.size() : 0, 0ull);     // (a tile is handled by one thread: no two threads share a word)
     uint64_t inter = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : inter)
     for (int tile = 0; tile < S.tiles_x * S.tiles_y; ++tile) {
@@ -450,6 +453,7 @@ template <class T> void render_forward(State<T>& S) {
                     C0 = C0 + S.rgb[3 * id] * w; C1 = C1 + S.rgb[3 * id + 1] * w; C2 = C2 + S.rgb[3 * id + 2] * w;
                     Tr = test_T;
                     last = contributor;
+                    if (S.record_masks) S.take_masks[4 * (size_t)j + rq] |= 1ull << rl;
                 }
                 const size_t pix = (size_t)y * W + x;
                 S.final_T[pix] = Tr; S.n_contrib[pix] = last; S.fragile[pix] = frag & 1; S.cap_fragile[pix] = (frag >> 1) & 1;

@@ -29,7 +29,7 @@ const void* get_array(dvso::State<T>& S, const std::string& name, uint64_t* coun
     DVSO_ARR("tiles_touched", S.tiles_touched) DVSO_ARR("rect", S.rect) DVSO_ARR("depth_bits", S.depth_bits)
     DVSO_ARR("offsets", S.offsets) DVSO_ARR("keys", S.keys) DVSO_ARR("vals", S.vals) DVSO_ARR("ranges", S.ranges)
     DVSO_ARR("out_color", S.out_color) DVSO_ARR("final_T", S.final_T) DVSO_ARR("n_contrib", S.n_contrib)
-    DVSO_ARR("fragile", S.fragile) DVSO_ARR("cap_fragile", S.cap_fragile)
+    DVSO_ARR("fragile", S.fragile) DVSO_ARR("cap_fragile", S.cap_fragile) DVSO_ARR("take_masks", S.take_masks)
     DVSO_ARR("dL_dmean2d", S.dL_dmean2d) DVSO_ARR("dL_dconic_opacity", S.dL_dconic_opacity)
     DVSO_ARR("dL_drgb", S.dL_drgb) DVSO_ARR("absgrad", S.absgrad)
     DVSO_ARR("g_pos", S.g_pos) DVSO_ARR("g_sh0", S.g_sh0) DVSO_ARR("g_shN", S.g_shN)
@@ -78,6 +78,12 @@ int dvso_set_replay(void* hp, const uint64_t* masks, uint64_t count) {
     Handle* h = (Handle*)hp;
     h->f.replay.assign(masks, masks + count); h->d.replay.assign(masks, masks + count);
     return 0;
+}
+
+// From now on every forward also records the decisions it took itself ("take_masks", [T][4] uint64: same layout as the HIP hook).
+void dvso_record_masks(void* hp, int on) {
+    Handle* h = (Handle*)hp;
+    h->f.record_masks = on != 0; h->d.record_masks = on != 0;
 }
 
 // dL_dout: [3,H,W] planar, float or double per the handle.

@@ -33,6 +33,7 @@ def _load():
         _lib.dvso_backward.restype = C.c_int
         _lib.dvso_backward.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dvso_set_grad_mode.argtypes = [C.c_void_p, C.c_int]
+        _lib.dvso_record_masks.argtypes = [C.c_void_p, C.c_int]
         _lib.dvso_set_replay.restype = C.c_int
         _lib.dvso_set_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         _lib.dvso_array.restype = C.c_void_p
@@ -50,10 +51,10 @@ def _load():
 
 _INT_DTYPES = {"radii": np.int32, "rect": np.int32, "flags": np.uint32, "tiles_touched": np.uint32,
                "depth_bits": np.uint32, "offsets": np.uint32, "keys": np.uint64, "vals": np.uint32,
-               "ranges": np.uint32, "n_contrib": np.uint32, "fragile": np.uint8, "cap_fragile": np.uint8}
+               "ranges": np.uint32, "n_contrib": np.uint32, "fragile": np.uint8, "cap_fragile": np.uint8, "take_masks": np.uint64}
 _SHAPES = {"mean2d": (-1, 2), "conic_opacity": (-1, 4), "rgb": (-1, 3), "rect": (-1, 4), "ranges": (-1, 2),
            "dL_dmean2d": (-1, 2), "dL_dconic_opacity": (-1, 4), "dL_drgb": (-1, 3), "absgrad": (-1, 2),
-           "g_pos": (-1, 3), "g_sh0": (-1, 3), "g_shN": (-1, 15, 3), "g_scale": (-1, 3), "g_rot": (-1, 4)}
+           "take_masks": (-1, 4), "g_pos": (-1, 3), "g_sh0": (-1, 3), "g_shN": (-1, 15, 3), "g_scale": (-1, 3), "g_rot": (-1, 4)}
 
 
 def set_threads(n):
@@ -86,6 +87,10 @@ class Oracle:
         rc = self.lib.dvso_forward(self.h, n, *[a.ctypes.data for a in arrs], C.addressof(cam), C.addressof(opts))
         assert rc == 0, "the recorded decisions do not belong to these tile lists" if rc == 2 else rc
         return self.get("out_color").reshape(3, self.H, self.W)
+
+    def record_masks(self, on=True):
+        """Every forward from now on records its own decisions: get("take_masks") -> uint64 [T, 4] (the layout of the HIP hook)."""
+        self.lib.dvso_record_masks(self.h, int(bool(on)))
 
     def set_replay(self, masks):
         """Decision replay: masks = uint64 [T, 4] recorded by the HIP forward (Rasterizer.record_decisions) — bit l of masks[j, q] says pixel
