@@ -42,13 +42,9 @@
 #ifndef TR_SKIP_EMPTY_STEPS
 #define TR_SKIP_EMPTY_STEPS 0      // a step in which no lane contributes could skip its second half — measured: 450 of 2.78 M steps per C3 view
 #endif                             // (the block test + per-block deepest contributor leave no empty steps); the branch only splits the schedule
-#ifndef TR_OWNER
-#define TR_OWNER 0         // 1: the table update of a round as ONE read-add-write for every (block group, entry) pair that owns its table row in
-#endif                     // this round (an owner byte per row, written and read back early in the round: whichever group's write lands last owns
-                           // the row), followed by a pass per group that still has losers — instead of always four serial passes
-#ifndef TR_PREFETCH
-#define TR_PREFETCH 0      // 1: wave 0 touches the NEXT batch's 64-B records (one dword each) while the current batch is walked, so that the
-#endif                     // staging gather of the next batch hits the cache instead of waiting a full memory round trip ahead of a barrier
+// (Round 4 measured two more variants of this kernel and dropped them — the next batch's records touched ahead of their gather, and an
+// owner byte per table row that lets conflict-free pairs update in one pass: DESIGN.md section 5.3, profiles/r04_a8_variants_ab.txt; their code
+// is in the history at commit cb18e80.)
 #ifndef TR_MINW
 #define TR_MINW 6          // waves per SIMD the kernel is compiled for (register cap 80; the LDS footprint allows six workgroups per CU)
 #endif
@@ -157,9 +153,6 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     __shared__ TrLds<BK> L;
     __shared__ float s_tab[4][(BK + 1) * 12];               // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
     __shared__ __attribute__((aligned(16))) float s_tb[4][TR_SLOTS * TR_SS];  // per wave: slot, plane (v5 | w), phase-1 lane
-#if TR_OWNER
-    __shared__ uint8_t s_own[4][BK + 8];                    // per wave and table row: the block group that owns the row in the current round
-#endif
     (void)bg_arg;
     const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;       // release builds: every `dbg &` test below folds away
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
@@ -242,11 +235,6 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         if (dbg & 4) return;
         const uint32_t jp = (uint32_t)__builtin_amdgcn_ds_bpermute(jaddr, (int)jpack);
         const int j = (int)((jp >> jshift) & 0xffu);
-#if TR_OWNER
-        s_own[wave][j] = (uint8_t)g2;                                     // (the four rows of a pair write the same value; LDS operations of a wave execute in order)
-        asm volatile("" ::: "memory");
-        const uint32_t owner = s_own[wave][j];                            // arrives under the arithmetic below
-#endif
         const tr_v4f V_ = *(lds_cv4f*)tbr_a, W_ = *(lds_cv4f*)(tbr_a + 256u);
         const float4 V = make_float4(V_.x, V_.y, V_.z, V_.w), Wv = make_float4(W_.x, W_.y, W_.z, W_.w);
         const float2 mean = *reinterpret_cast<const float2*>(&L.ea[j]);
@@ -316,51 +304,23 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         lds_float* const slot = (lds_float*)slot_a;
         if (dbg & 2048) { asm volatile("" : : "v"(q0), "v"(q1), "v"(q2), "v"(slot_a)); return; }     // timing only: no table update
         if (dbg & 8192) { slot[0] += q0; slot[4] += q1; slot[8] += q2; return; }                      // timing only: ONE read-add-write for all four groups (conflicts ignored)
-#if TR_OWNER
-        // every row has exactly one owner among the groups that hold it in this round: the owners' updates touch distinct addresses and go
-        // in one pass (the sink row of the dummy entry takes whatever arrives); what is left — a second or third group on the same row — is
-        // rare and goes group by group, skipped when empty
-        const bool win = owner == (uint32_t)g2 || j == BK;
-        if (win) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        if (__builtin_amdgcn_ballot_w64(!win) != 0ull) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bool mine = !win && g2 == g;
-                if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
-                    if (mine) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("" ::: "memory");
-                }
-            }
-        }
-#else
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g2 == g) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
         }
-#endif
     };
 
     const int nbatch = (int)((todo + BK - 1) / BK);
     const float tile_x0 = (float)(tx * DVS_TILE), tile_y0 = (float)(ty * DVS_TILE);
     uint32_t id_stage = tr_load_id<BK>(sorted_splat, range.x + (nbatch - 1) * BK, min(BK, (int)todo - (nbatch - 1) * BK));
-#if TR_PREFETCH
-    uint32_t id_next = nbatch > 1 ? tr_load_id<BK>(sorted_splat, range.x + (nbatch - 2) * BK, BK) : 0u;      // ids run two batches ahead
-#endif
     for (int b = nbatch - 1; b >= 0; --b) {
         const int base = b * BK;
         const int cnt = min(BK, (int)todo - base);
         // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
         tr_stage<BK>(L, splat2d, id_stage, cnt, base, b & 1, tile_x0, tile_y0, dbg);
         if (!(dbg & 256)) __syncthreads();                  // batch staged; the tables are zero again        (dbg 256: timing of a barrier-free batch loop — wrong results)
-#if TR_PREFETCH
-        float pf = 0.f;                                     // one dword of each record of batch b - 1: the line is in the cache when tr_stage asks for it
-        if (wave == 0 && b > 0) pf = reinterpret_cast<const float*>(splat2d)[16 * (size_t)id_next];
-#endif
         const int len = (int)L.cnt[blk1];
         int nmax = len;
         nmax = max(nmax, __shfl_xor(nmax, 16, 64));
@@ -438,13 +398,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
             flush(jpack);
         }
         if (!(dbg & 256)) __syncthreads();                  // tables complete; nobody reads the staged entries or lists any more
-#if TR_PREFETCH
-        asm volatile("" : : "v"(pf));                       // (keeps the touch alive; it has long arrived)
-        id_stage = id_next;
-        if (b > 1) id_next = tr_load_id<BK>(sorted_splat, range.x + (b - 2) * BK, BK);
-#else
         if (b > 0) id_stage = tr_load_id<BK>(sorted_splat, range.x + (b - 1) * BK, BK);     // the next batch's ids arrive under the publish
-#endif
         // the tile's total per touched (entry, value): ONE global atomic each — consecutive threads add consecutive floats of a row.
         // The moment and abs-grad sums were taken over v5 = G dL/dalpha; the row contract wants them over opacity * v5.
         for (int e = threadIdx.x; e < ((dbg & 128) ? 0 : cnt * 12); e += RB) {
