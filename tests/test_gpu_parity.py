@@ -159,13 +159,25 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     orp.set_replay(masks)
     img_r = orp.forward(P, cam, sh_degree=deg, antialias=aa)
     assert np.array_equal(orp.get("n_contrib"), saved["n_contrib"]), "replayed decisions do not reproduce n_contrib"
-    # EVERY pixel now, fragile or not, against fp64: 1e-4 relative; the absolute floor is 2e-6 of the image maximum (against the fp32
-    # oracle above it is 1e-6: a pixel with hundreds of contributors carries that much plain fp32 summation error; measured worst over
-    # the configurations: 1.05e-6)
-    m, worst = rel_close(img, img_r, 1e-4, 2e-6)
+    # A7 on EVERY pixel, fragile or not: against the fp32 oracle replaying the same decisions — the specification of the composite
+    # arithmetic on bit-identical projected splats (an fp64 projection moves a sharp splat's alpha by up to 1e-4 through the rounding of
+    # its fp32 mean alone, so the fp64 replay is the reference of the gradients below, not of a transmittance that is a product of
+    # hundreds of (1 - alpha))
+    orp32 = None
+    if same_lists:
+        orp32 = oracle_mod.Oracle(np.float32)
+        orp32.set_replay(masks)
+        img_r32, fT_r32 = orp32.forward(P, cam, sh_degree=deg, antialias=aa), None
+        fT_r32 = orp32.get("final_T")
+        assert np.array_equal(orp32.get("n_contrib"), saved["n_contrib"])
+    else:
+        img_r32, fT_r32 = img_r, orp.get("final_T")
+    m, worst = rel_close(img, img_r32, 1e-4, 1e-6)
     assert m.all(), f"rgb (replay, all pixels) worst {worst}"
-    m, worst = rel_close(saved["final_T"], orp.get("final_T"), 1e-4, 2e-6)
+    m, worst = rel_close(saved["final_T"], fT_r32, 1e-4, 1e-6)
     assert m.all(), f"final_T (replay, all pixels) worst {worst}"
+    m, worst = rel_close(img, img_r, 1e-3, 1e-5)                       # and the fp64 replay at the looser bar that input rounding allows
+    assert m.all(), f"rgb (fp64 replay, all pixels) worst {worst}"
     frag_any = frag | o64.get("fragile").astype(bool)
     capf = orp.get("cap_fragile").astype(bool)
     tainted = np.zeros(n, bool)
@@ -184,9 +196,10 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     # what the replay cannot pin is bounded for EVERY configuration (no configuration looser than 1e-4 on > 10 %)
     assert tainted.mean() < 0.10, tainted.mean()
     clean = ~tainted
+    clean_early = clean
     report = {"config": name, "n": n, "visible": int((saved["radii"] > 0).sum()), "T": int(rast.num_rendered),
               "fragile_pixel_fraction": float(frag_any.mean()), "tainted_splat_fraction": float(tainted.mean()),
-              "decision_replay": "fp64" if same_lists else "fp32 (fp64 bins differently)", "cap_fragile_pixel_fraction": float(capf.mean()), "runs": {}}
+              "decision_replay": "fp32 strict + fp64 wide" if same_lists else "fp32 (fp64 bins differently)", "cap_fragile_pixel_fraction": float(capf.mean()), "runs": {}}
 
     # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
     # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-3 relative L2
@@ -217,10 +230,21 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     culled = saved["radii"] == 0
     oracle_grads = {}
     for mode in (0, 1):
-        # strict reference: the replaying oracle (the HIP path's own decisions); the plain fp32 oracle stays the reference of the few
-        # cap-tainted splats
-        ref64 = {k: v.copy() for k, v in orp.backward(dL, grad_mode=mode).items()}
-        inter64 = {k: orp.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
+        # strict reference: the fp32 oracle replaying the HIP path's own decisions — the specification evaluated on bit-identical
+        # projected splats with identical contributor sets (what is compared is the arithmetic alone). The fp64 replay is checked
+        # beside it at the bar the fp32 rounding of the INPUTS allows: a splat behind hundreds of contributors inherits the relative
+        # error those accumulate in T when each alpha moves by 1e-4 with the rounding of its mean (relative L2 < 1e-4 per group,
+        # every element within 10x the strict tolerance). The plain fp32 oracle stays the reference of the few cap-tainted splats.
+        strict = orp32 if same_lists else orp
+        ref64 = {k: v.astype(np.float64) for k, v in strict.backward(dL.astype(strict.dtype), grad_mode=mode).items()}
+        inter64 = {k: strict.get(k).astype(np.float64) for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
+        if same_lists:
+            wide = {k: v.copy() for k, v in orp.backward(dL, grad_mode=mode).items()}
+            for k in KEYS:
+                a, b = ref64[k][clean_early], wide[k][clean_early]
+                l2 = np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
+                assert l2 < 1e-4, f"fp32 replay vs fp64 replay, mode {mode}, {k}: relative L2 {l2}"
+                assert (np.abs(a - b) <= 10 * (1e-4 * np.abs(b) + 1e-5 * np.abs(wide[k]).max())).all(), (mode, k)
         ref32 = {k: v.copy() for k, v in o.backward(dL, grad_mode=mode).items()}
         inter32 = {k: o.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
         oracle_grads[mode] = ref64
