@@ -213,9 +213,11 @@ int tcp_fail(const char* who, const char* what) {
 template <class Combine>
 int tcp_collective(dvs_comm* c, hipStream_t st, const void* dev_in, void* dev_out, size_t bytes, bool gather, Combine combine, const char* who) {
     const size_t out_bytes = gather ? bytes * (size_t)c->world : bytes;
-    if (hipStreamSynchronize(st) != hipSuccess) return tcp_fail(who, "hipStreamSynchronize failed");
+    const bool host = c->device < 0;                        // device -1: the buffers are HOST memory (CPU tests of the collectives' logic)
+    if (!host && hipStreamSynchronize(st) != hipSuccess) return tcp_fail(who, "hipStreamSynchronize failed");
     c->h_send.resize(bytes); c->h_recv.resize(out_bytes);
-    if (hipMemcpy(c->h_send.data(), dev_in, bytes, hipMemcpyDeviceToHost) != hipSuccess) return tcp_fail(who, "device -> host copy failed");
+    if (host) memcpy(c->h_send.data(), dev_in, bytes);
+    else if (hipMemcpy(c->h_send.data(), dev_in, bytes, hipMemcpyDeviceToHost) != hipSuccess) return tcp_fail(who, "device -> host copy failed");
     if (c->rank == 0) {
         std::vector<char> in(bytes);
         if (gather) memcpy(c->h_recv.data(), c->h_send.data(), bytes); else memcpy(c->h_recv.data(), c->h_send.data(), bytes);
@@ -230,7 +232,8 @@ int tcp_collective(dvs_comm* c, hipStream_t st, const void* dev_in, void* dev_ou
         if (!send_all(c->fds[0], c->h_send.data(), bytes) || !recv_all(c->fds[0], c->h_recv.data(), out_bytes))
             return tcp_fail(who, "rank 0 closed its socket or timed out");
     }
-    if (hipMemcpy(dev_out, c->h_recv.data(), out_bytes, hipMemcpyHostToDevice) != hipSuccess) return tcp_fail(who, "host -> device copy failed");
+    if (host) memcpy(dev_out, c->h_recv.data(), out_bytes);
+    else if (hipMemcpy(dev_out, c->h_recv.data(), out_bytes, hipMemcpyHostToDevice) != hipSuccess) return tcp_fail(who, "host -> device copy failed");
     return DVS_OK;
 }
 void sum_f32(char* acc, const char* in, size_t bytes) {
@@ -281,7 +284,8 @@ dvs_comm* dvs_comm_create(int device, int rank, int world, const char* master_ad
     resolve_rendezvous(rank, world, master_addr, master_port);
     if (rank < 0 || rank >= world) { dvs_set_last_error("dvs_comm_create: rank outside [0, world)"); return nullptr; }
     if (want_tcp_backend()) {
-        if (hipSetDevice(device) != hipSuccess) { dvs_set_last_error("dvs_comm_create: hipSetDevice failed"); return nullptr; }
+        // (device -1 with the test backend: no HIP at all, the collectives then take HOST buffers — tests/test_comm_bootstrap.py)
+        if (device >= 0 && hipSetDevice(device) != hipSuccess) { dvs_set_last_error("dvs_comm_create: hipSetDevice failed"); return nullptr; }
         dvs_comm* c = new dvs_comm();
         c->device = device; c->rank = rank; c->world = world; c->tcp = true; c->op_timeout = bootstrap_timeout();
         char id[128] = {0};
@@ -341,6 +345,12 @@ int dvs_comm_reduce_scatter_sum_f32(dvs_comm* c, void* stream, const float* send
     if (!recv_count) return DVS_OK;
     if (c->tcp) {          // all-reduce on the host, then this rank's slice
         const size_t total = recv_count * (size_t)c->world;
+        if (c->device < 0) {                             // host buffers
+            std::vector<float> tmp(send, send + total);
+            int r = c->world > 1 ? tcp_collective(c, nullptr, tmp.data(), tmp.data(), total * 4, false, sum_f32, "dvs_comm_reduce_scatter_sum_f32") : DVS_OK;
+            if (r == DVS_OK) memcpy(recv, tmp.data() + recv_count * (size_t)c->rank, recv_count * 4);
+            return r;
+        }
         float* tmp = nullptr;
         if (hipMalloc((void**)&tmp, total * 4) != hipSuccess) return tcp_fail("dvs_comm_reduce_scatter_sum_f32", "hipMalloc failed");
         int r = hipMemcpyAsync(tmp, send, total * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? DVS_OK : DVS_ERR_HIP;
@@ -356,7 +366,10 @@ int dvs_comm_all_gather_f32(dvs_comm* c, void* stream, const float* send, float*
     if (!c || (send_count && (!send || !recv))) { dvs_set_last_error("dvs_comm_all_gather_f32: null argument"); return DVS_ERR_INVALID; }
     if (!send_count) return DVS_OK;
     if (c->tcp) {
-        if (c->world == 1) return hipMemcpyAsync(recv, send, send_count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+        if (c->world == 1) {
+            if (c->device < 0) { memcpy(recv, send, send_count * 4); return DVS_OK; }
+            return hipMemcpyAsync(recv, send, send_count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+        }
         return tcp_collective(c, (hipStream_t)stream, send, recv, send_count * 4, true, keep, "dvs_comm_all_gather_f32");
     }
     RCCLCHECK(g_rccl.AllGather(send, recv, send_count, rcclFloat32, c->comm, (hipStream_t)stream));
@@ -379,6 +392,12 @@ int dvs_comm_broadcast(dvs_comm* c, void* stream, void* buf, size_t bytes, int r
     if (!bytes) return DVS_OK;
     if (c->tcp) {          // gather everything on rank 0, keep the root's slot (test backend: simplicity over bytes)
         if (c->world == 1) return DVS_OK;
+        if (c->device < 0) {                             // host buffers
+            std::vector<char> all(bytes * (size_t)c->world);
+            int r = tcp_collective(c, nullptr, buf, all.data(), bytes, true, keep, "dvs_comm_broadcast");
+            if (r == DVS_OK) memcpy(buf, all.data() + bytes * (size_t)root, bytes);
+            return r;
+        }
         char* tmp = nullptr;
         if (hipMalloc((void**)&tmp, bytes * (size_t)c->world) != hipSuccess) return tcp_fail("dvs_comm_broadcast", "hipMalloc failed");
         int r = tcp_collective(c, (hipStream_t)stream, buf, tmp, bytes, true, keep, "dvs_comm_broadcast");

@@ -16,7 +16,8 @@
  * DVS_COMM_BACKEND=tcp selects a TEST-ONLY backend: the same calls, executed host-staged over the bootstrap sockets (star on rank 0,
  * sums formed in rank order, every call synchronous). It needs neither librccl nor distinct devices per rank, which is the point: two
  * ranks of libgstrain.so can share the one GPU of a test box (tests/test_gpu_multirank.py). It is announced on stderr when created and
- * must never be used for measurements.
+ * must never be used for measurements. With device = -1 it touches no HIP at all and the collectives take HOST buffers: the logic of
+ * every collective is then testable on a machine without a GPU (tests/test_comm_bootstrap.py, three ranks).
  */
 #ifndef DVS_COMM_H
 #define DVS_COMM_H

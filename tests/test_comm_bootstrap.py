@@ -78,3 +78,62 @@ def test_missing_rank_times_out_with_an_error():
     assert rc != 0 and "timed out" in msg and time.time() - t0 < 30
     rc, _, msg = _result(_spawn(1, 2, port, {"DVS_COMM_TIMEOUT_S": "2"}), timeout=60)      # nobody serves
     assert rc != 0 and "no RCCL id" in msg
+
+
+COLL_CODE = r"""
+import ctypes as C, os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["DVS_ROOT"])
+import divshot_amd as dv
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+c = dv.lib.dvs_comm_create(-1, -1, -1, None, 0)          # device -1 + DVS_COMM_BACKEND=tcp: host buffers, no HIP
+assert c, dv.lib.dvs_last_error()
+res = {}
+a = (np.arange(1000, dtype=np.float32) * (rank + 1) + np.float32(0.1 * rank))
+want = sum((np.arange(1000, dtype=np.float32) * (r + 1) + np.float32(0.1 * r)) for r in range(world))      # rank order: the sum the star forms
+assert dv.lib.dvs_comm_all_reduce_sum_f32(c, None, a.ctypes.data, a.size) == 0
+res["allreduce_bits_equal_rank_order_sum"] = bool(np.array_equal(a, want.astype(np.float32)))
+m = np.array([rank, 10 - rank, 5], np.int32)
+assert dv.lib.dvs_comm_all_reduce_max_i32(c, None, m.ctypes.data, m.size) == 0
+res["max"] = m.tolist()
+s = np.full(7, rank + 1, np.float32); g = np.zeros(7 * world, np.float32)
+assert dv.lib.dvs_comm_all_gather_f32(c, None, s.ctypes.data, g.ctypes.data, s.size) == 0
+res["gather"] = g.reshape(world, 7)[:, 0].tolist()
+send = np.arange(4 * world, dtype=np.float32) + rank; recv = np.zeros(4, np.float32)
+assert dv.lib.dvs_comm_reduce_scatter_sum_f32(c, None, send.ctypes.data, recv.ctypes.data, recv.size) == 0
+res["reduce_scatter"] = recv.tolist()
+b = np.full(5, 7 if rank == 1 else -1, np.int32)
+assert dv.lib.dvs_comm_broadcast(c, None, b.ctypes.data, b.nbytes, 1) == 0
+res["broadcast"] = b.tolist()
+assert dv.lib.dvs_comm_group_start(c) == 0 and dv.lib.dvs_comm_group_end(c) == 0
+dv.lib.dvs_comm_destroy(c)
+print("RESULT 0 " + json.dumps(res).replace(" ", ""))
+"""
+
+
+def test_tcp_backend_collectives_three_ranks_on_host_buffers():
+    """The TEST backend of include/dvs_comm.h (DVS_COMM_BACKEND=tcp) with device = -1: every collective of the data-parallel step on host
+    buffers, three ranks, no GPU — sums formed in rank order (all ranks receive the same bits), max, all-gather slot order,
+    reduce-scatter slices, broadcast from a non-zero root."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, DVS_ROOT=ROOT, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DVS_COMM_BACKEND="tcp",
+                   DVS_COMM_TIMEOUT_S="60")
+        env.pop("DVS_COMM_PORT", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", COLL_CODE], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=180)
+        line = [l for l in so.splitlines() if l.startswith("RESULT 0 ")]
+        assert line, so + se
+        outs.append(json.loads(line[-1][9:]))
+    for r, res in enumerate(outs):
+        assert res["allreduce_bits_equal_rank_order_sum"]
+        assert res["max"] == [2, 10, 5]
+        assert res["gather"] == [1.0, 2.0, 3.0]
+        want = [float(sum(4 * r + k + q for q in range(3))) for k in range(4)]
+        assert res["reduce_scatter"] == want, (r, res["reduce_scatter"], want)
+        assert res["broadcast"] == [7] * 5
+    assert outs[0] == {**outs[0]} and outs[0]["allreduce_bits_equal_rank_order_sum"]
