@@ -43,11 +43,9 @@
 #define TR_SKIP_EMPTY_STEPS 0      // a step in which no lane contributes could skip its second half — measured: 450 of 2.78 M steps per C3 view
 #endif                             // (the block test + per-block deepest contributor leave no empty steps); the branch only splits the schedule
 // (Round 4 measured two more variants of this kernel and dropped them — the next batch's records touched ahead of their gather, and an
-// owner byte per table row that lets conflict-free pairs update in one pass: DESIGN.md section 5.3, profiles/r04_a8_variants_ab.txt; their code
-// is in the history at commit cb18e80.)
-#ifndef TR_AUTONOMOUS
-#define TR_AUTONOMOUS 0
-#endif
+// owner byte per table row that lets conflict-free pairs update in one pass (code in the history at commit cb18e80) — and a wave-autonomous
+// form of the whole kernel, one wave per workgroup without any workgroup barrier (commit 7484d16; 25 % slower): DESIGN.md section 5.3,
+// profiles/r04_a8_variants_ab.txt, r04_a8_autonomous_ab.txt.)
 #ifndef TR_MINW
 #define TR_MINW 6          // waves per SIMD the kernel is compiled for (register cap 80; the LDS footprint allows six workgroups per CU)
 #endif
@@ -417,319 +415,6 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     }
 }
 
-#if TR_AUTONOMOUS
-
-// ---- TR_AUTONOMOUS (round-4 experiment): every wave stages, walks and publishes its OWN 8x8 quadrant — one wave per
-// workgroup, no workgroup barrier anywhere; the price is a private copy of the staged batch per wave, every record gathered by each of the
-// (on average 1.8) quadrants it reaches... in fact by all four, and one publish per (quadrant, entry) instead of one per (tile, entry).
-#ifndef TR_QMINW
-#define TR_QMINW 5
-#endif
-template <int BK>
-struct __attribute__((aligned(16))) TrLdsQ {
-    float4 ea[BK + 1], eb[BK + 1], ec[BK + 1];
-    uint2 idop[2][BK];
-    uint8_t list[(BK + 1) * 4];   // element k (1-based) of block g of the quadrant at k * 4 + g; row 0 = sentinels
-    uint32_t cnt[4];
-};
-template <int BK>
-__device__ __forceinline__ void tr_stage_q(TrLdsQ<BK>& L, const float4* __restrict__ splat2d, uint32_t id, int cnt, int base, int quad,
-                                           const uint32_t bl[4], float tile_x0, float tile_y0) {
-    static_assert(BK == 64, "one lane per entry");
-    const int e = threadIdx.x;
-    uint32_t hits = 0;
-    if (e < cnt) {
-        const float4 r0 = splat2d[4 * (size_t)id], r1 = splat2d[4 * (size_t)id + 1], r2 = splat2d[4 * (size_t)id + 2], r3 = splat2d[4 * (size_t)id + 3];
-        const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
-        L.ea[e] = make_float4(r0.x, r0.y, -0.72134752044448170f * a, -1.4426950408889634f * b);
-        L.eb[e] = make_float4(-0.72134752044448170f * c, op, r1.z, r1.w);
-        L.ec[e] = make_float4(r2.x, a, b, c);
-        L.idop[base / BK & 1][e] = make_uint2(id, __float_as_uint(op));
-        const float bound = r2.w, det_c = r3.x, det_a = r3.y, nb_c = r3.z, nb_a = r3.w;
-        const float ox = tile_x0 - r0.x + 8.f * (float)(quad & 1), oy = tile_y0 - r0.y + 8.f * (float)(quad >> 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0 = ox + 4.f * (float)(i & 1), x1 = x0 + 3.f, y0 = oy + 4.f * (float)(i >> 1), y1 = y0 + 3.f;
-            const bool vin = x0 <= 0.f && x1 >= 0.f, hin = y0 <= 0.f && y1 >= 0.f;
-            const float xe = x0 > 0.f ? x0 : x1, ye = y0 > 0.f ? y0 : y1;
-            const float vy = nb_c * xe, vbase = vin ? __builtin_inff() : xe * xe * det_c;
-            const float hx = nb_a * ye, hbase = hin ? __builtin_inff() : ye * ye * det_a;
-            const float ty_ = fminf(fmaxf(vy, y0), y1) - vy, tx_ = fminf(fmaxf(hx, x0), x1) - hx;
-            const float ev = __builtin_fmaf(c * ty_, ty_, vbase), eh = __builtin_fmaf(a * tx_, tx_, hbase);
-            const float qm = (vin && hin) ? 0.f : fminf(ev, eh);
-            bool h = !(qm > bound);
-            h = h && ((uint32_t)(base + e) < bl[i]);
-            hits |= h ? (1u << i) : 0u;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool hit = (hits & (1u << i)) != 0u;
-        const uint64_t m = __ballot(hit);
-        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (hit) L.list[(rk + 1u) * 4u + (uint32_t)i] = (uint8_t)e;
-        if (e == 0) L.cnt[i] = (uint32_t)__popcll(m);
-    }
-}
-template <bool ABSGRAD, bool LINEAGE, int BK>
-__global__ void __launch_bounds__(64, TR_QMINW)
-k_render_bwd_trq(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
-                int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
-                const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
-                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
-                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg_arg /*experiment builds: ablation bits (timing only)*/,
-                const uint32_t* __restrict__ live_splat /*k_render_fwd's compacted lists (entries that reach the tile), or null*/,
-                const uint32_t* __restrict__ live_pos /*list position -> position in the compacted list*/) {
-    __shared__ TrLdsQ<BK> L;                                // ONE wave per workgroup: its own copy of the staged batch, its own lists, table and buffer
-    __shared__ float s_tab[1][(BK + 1) * 12];
-    __shared__ __attribute__((aligned(16))) float s_tb[1][TR_SLOTS * TR_SS];
-    (void)bg_arg;
-    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;       // release builds: every `dbg &` test below folds away
-    // four consecutive workgroups of an XCD's band = the four quadrants of one tile (they share its list and records in that XCD's L2)
-    const int kq = blockIdx.x >> 3;
-    const int tile_g = (blockIdx.x & 7) * ((num_tiles + 7) >> 3) + (kq >> 2);
-    if (tile_g >= num_tiles || (kq >> 2) >= ((num_tiles + 7) >> 3)) return;
-    const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
-    const float3 bgv = dvs_load_bg(view);
-    final_T += (size_t)view * W * H; n_contrib += (size_t)view * W * H; dL_dout += (size_t)view * 3 * W * H;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int wave = kq & 3 /* the quadrant */, lane = threadIdx.x;
-    const size_t P = (size_t)W * H;
-    // phase-1 role: group g1 = lane >> 4 (one 16-lane row = one 4x4 block of the wave's 8x8 quadrant), pixel i = lane & 15
-    const int g1 = lane >> 4, pi = lane & 15;
-    const int bx1 = 2 * (wave & 1) + (g1 & 1), by1 = 2 * (wave >> 1) + (g1 >> 1), blk1 = by1 * 4 + bx1;
-    const int px = tx * DVS_TILE + 4 * bx1 + (pi & 3), py = ty * DVS_TILE + 4 * by1 + (pi >> 2);
-    const bool inside = px < W && py < H;
-    const size_t pix = (size_t)py * W + px;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile_g];
-    // phase-2 role: pixel row r = lane >> 4, slot s = (lane >> 2) & 3, block g2 = lane & 3
-    const int r2 = lane >> 4, s2 = (lane >> 2) & 3, g2 = lane & 3;
-    const int bx2 = 2 * (wave & 1) + (g2 & 1), by2 = 2 * (wave >> 1) + (g2 >> 1);
-    const int X0 = tx * DVS_TILE + 4 * bx2, Y0 = ty * DVS_TILE + 4 * by2 + r2;
-    const float X0f = (float)X0, Y0f = (float)Y0;
-    float d2[4][3];                                           // upstream gradient of the four pixels (X0 + x, Y0) this lane sums in phase 2
-#pragma unroll                                                // (measured: fetching them per round instead — three global loads, or twelve
-    for (int x = 0; x < 4; ++x) {                             //  ds_bpermute from the phase-1 lanes — doubles the cost of a round)
-        const bool in2 = X0 + x < W && Y0 < H;
-        const size_t q = (size_t)Y0 * W + X0 + x;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) d2[x][c] = in2 ? dL_dout[c * P + q] : 0.f;
-    }
-    const int perm_r = (r2 == 1) ? 2 : (r2 == 2) ? 1 : r2;    // value index inside each packed register after the two swaps
-    const int xaddr = (lane ^ 32) << 2;
-    const int jaddr = (16 * g2) << 2;                         // any lane of phase-1 row g2 holds that group's slot -> entry map
-    const uint32_t jshift = 8u * (uint32_t)(TR_SLOTS - 1 - s2);
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    uint32_t last = inside ? n_contrib[pix] : 0u;
-    if (live_pos) {                                           // walk the forward's live list: same entries in the same order minus those that
-        if (last > 0u) last = live_pos[range.x + last - 1u] + 1u;     // cannot reach the tile; a contributor is always on it
-        sorted_splat = live_splat;
-    }
-    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f;
-    if (inside) { dLp0 = dL_dout[pix]; dLp1 = dL_dout[P + pix]; dLp2 = dL_dout[2 * P + pix]; }
-    const float bg_dot = (bgv.x * dLp0 + bgv.y * dLp1) + bgv.z * dLp2;
-
-    // deepest contributor per block (= per 16-lane row) and of the tile
-    uint32_t bmax = last;
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, d, 64));
-    uint32_t bl[4];                                            // deepest contributor of each of the quadrant's four blocks (wave-uniform)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bl[g] = (uint32_t)__builtin_amdgcn_readlane((int)bmax, 16 * g);
-    for (int e = lane; e < (BK + 1) * 12; e += 64) s_tab[0][e] = 0.f;
-    if (lane < 4) L.list[lane] = (uint8_t)BK;
-    if (lane == 0) { L.ea[BK] = make_float4(0.f, 0.f, 0.f, 0.f); L.eb[BK] = make_float4(0.f, 0.f, 0.f, 0.f); L.ec[BK] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t todo = max(max(bl[0], bl[1]), max(bl[2], bl[3]));     // of THIS quadrant: a quadrant that saturates early stops early
-    if (todo == 0 || (dbg & 64)) return;
-
-    float T = T_final;
-    float D = T_final * bg_dot;          // see k_render_bwd: one scalar of "colour behind" state suffices
-    const uint32_t tb_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_tb[0][0]);   // LDS byte offset of the wave's buffer (low half of the flat address), wave-uniform:
-                                                                          // phase 1 writes (v5, w) of slot s, lane l at floats [TR_SS s + l], [TR_SS s + 64 + l]
-    // LDS byte addresses kept as opaque 32-bit values (the low half of a flat LDS address is the LDS offset): the compiler otherwise
-    // rebuilds them from two registers in every round
-    typedef __attribute__((address_space(3))) float lds_float;
-    typedef float tr_v4f __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) const tr_v4f lds_cv4f;
-    uint32_t tbr_a = (uint32_t)(uintptr_t)&s_tb[0][TR_SS * s2 + 16 * g2 + 4 * r2];   // phase 2 reads its row of four pixels: v5 at floats 0..3, w at 64..67
-    uint32_t tabw_a = (uint32_t)(uintptr_t)&s_tab[0][perm_r];
-    asm("" : "+v"(tbr_a), "+v"(tabw_a));
-    const uint8_t* const lbase = &L.list[0];
-    (void)blk1;
-
-    // phase 2: the wave's TR_SLOTS x 4 (slot, block) pairs, four lanes (pixel rows) per pair
-    auto flush = [&](uint32_t jpack) {
-        if (dbg & 4) return;
-        const uint32_t jp = (uint32_t)__builtin_amdgcn_ds_bpermute(jaddr, (int)jpack);
-        const int j = (int)((jp >> jshift) & 0xffu);
-        const tr_v4f V_ = *(lds_cv4f*)tbr_a, W_ = *(lds_cv4f*)(tbr_a + 256u);
-        const float4 V = make_float4(V_.x, V_.y, V_.z, V_.w), Wv = make_float4(W_.x, W_.y, W_.z, W_.w);
-        const float2 mean = *reinterpret_cast<const float2*>(&L.ea[j]);
-        const float4 cq = L.ec[j];                                        // colour b | conic a, b, c
-        asm("" : : "v"(cq.x));                                            // (keeps the read ONE ds_read_b128: without a use of .x it is split into
-                                                                          //  two reads whose offsets need an extra address add)
-        const float Dx = mean.x - X0f, Dy = mean.y - Y0f;                 // d = mean - pixel for the row's first pixel; pixel x: Dx - x
-        if (dbg & 1024) {                                                 // timing only: a round without its arithmetic (what a matrix-pipe version could at best save)
-            const float h0 = swap32_add(V.x, V.y), h1 = swap32_add(V.z, V.w), h2 = swap32_add(Wv.x, Wv.y), h3 = swap32_add(Wv.z, Wv.w);
-            const float h4 = swap32_add(Dx, Dy), h5 = Dx + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(Dy)));
-            const float q0 = swap16_add(h0, h1), q1 = swap16_add(h2, h3), q2 = swap16_add(h4, h5);
-            uint32_t slot_a;
-            asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(slot_a) : "v"(j), "v"(tabw_a));
-            lds_float* const slot = (lds_float*)slot_a;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g2 == g) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-            }
-            return;
-        }
-        const float A0 = (V.x + V.y) + (V.z + V.w);
-        const float B0 = __builtin_fmaf(3.f, V.w, __builtin_fmaf(2.f, V.z, V.y));
-        const float C0 = __builtin_fmaf(9.f, V.w, __builtin_fmaf(4.f, V.z, V.y));
-        float v[12];
-        v[0] = __builtin_fmaf(Dx, A0, -B0);                               // S_x  = sum v5 (Dx - x)
-        v[1] = Dy * A0;                                                   // S_y
-        v[2] = __builtin_fmaf(Dx, v[0], -__builtin_fmaf(Dx, B0, -C0));    // S_xx = sum v5 (Dx - x)^2 = Dx S_x - (Dx B - C)
-        v[3] = Dy * v[0];                                                 // S_xy
-        v[4] = Dy * v[1];                                                 // S_yy
-        v[5] = A0;                                                        // S_o
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            v[6 + c] = __builtin_fmaf(Wv.w, d2[3][c], __builtin_fmaf(Wv.z, d2[2][c], __builtin_fmaf(Wv.y, d2[1][c], Wv.x * d2[0][c])));
-        if (ABSGRAD) {
-            // |dL/dmean2D| per pixel = |v5| |(a dx + b dy, b dx + c dy)| (times the opacity, applied at publish); linear in x
-            const float gx0 = __builtin_fmaf(cq.y, Dx, cq.z * Dy), gy0 = __builtin_fmaf(cq.z, Dx, cq.w * Dy);
-            const float gx1 = gx0 - cq.y, gx2 = gx1 - cq.y, gx3 = gx2 - cq.y;
-            const float gy1 = gy0 - cq.z, gy2 = gy1 - cq.z, gy3 = gy2 - cq.z;
-            v[9] = __builtin_fmaf(fabsf(V.w), fabsf(gx3), __builtin_fmaf(fabsf(V.z), fabsf(gx2), __builtin_fmaf(fabsf(V.y), fabsf(gx1), fabsf(V.x) * fabsf(gx0))));
-            v[10] = __builtin_fmaf(fabsf(V.w), fabsf(gy3), __builtin_fmaf(fabsf(V.z), fabsf(gy2), __builtin_fmaf(fabsf(V.y), fabsf(gy1), fabsf(V.x) * fabsf(gy0))));
-        } else { v[9] = 0.f; v[10] = 0.f; }
-        v[11] = 0.f;
-        // fold the four pixel rows (the four 16-lane rows of the wave) with the packing swaps: afterwards row r holds, in q[k], the
-        // total of value 4 k + perm(r) of its (block, slot) pair
-        float q0, q1, q2;
-        if (dbg & 4096) {                                                 // timing only: the round without its packing swaps
-            q0 = (v[0] + v[1]) + (v[2] + v[3]); q1 = (v[4] + v[5]) + (v[6] + v[7]); q2 = (v[8] + v[9]) + v[10];
-        } else {
-        const float h0 = swap32_add(v[0], v[1]), h1 = swap32_add(v[2], v[3]), h2 = swap32_add(v[4], v[5]);
-        const float h3 = swap32_add(v[6], v[7]);
-        float h4, h5;
-        if (ABSGRAD) {
-            h4 = swap32_add(v[8], v[9]);
-            h5 = v[10] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[10])));
-        } else {
-            h4 = v[8] + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v[8])));
-            h5 = 0.f;
-        }
-        q0 = swap16_add(h0, h1); q1 = swap16_add(h2, h3); q2 = swap16_add(h4, h5);
-        }
-        // one block group at a time: two groups may hold the same entry (measured: in nearly every round); LDS operations of one wave
-        // execute in order, so a later group sees an earlier group's write
-        uint32_t slot_a;                                                  // = tabw_a + 48 j
-        asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(slot_a) : "v"(j), "v"(tabw_a));
-        lds_float* const slot = (lds_float*)slot_a;
-        if (dbg & 2048) { asm volatile("" : : "v"(q0), "v"(q1), "v"(q2), "v"(slot_a)); return; }     // timing only: no table update
-        if (dbg & 8192) { slot[0] += q0; slot[4] += q1; slot[8] += q2; return; }                      // timing only: ONE read-add-write for all four groups (conflicts ignored)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g2 == g) { slot[0] += q0; slot[4] += q1; slot[8] += q2; }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-        }
-    };
-
-    const int nbatch = (int)((todo + BK - 1) / BK);
-    const float tile_x0 = (float)(tx * DVS_TILE), tile_y0 = (float)(ty * DVS_TILE);
-    uint32_t id_stage = tr_load_id<BK>(sorted_splat, range.x + (nbatch - 1) * BK, min(BK, (int)todo - (nbatch - 1) * BK));
-    for (int b = nbatch - 1; b >= 0; --b) {
-        const int base = b * BK;
-        const int cnt = min(BK, (int)todo - base);
-        // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
-        tr_stage_q<BK>(L, splat2d, id_stage, cnt, base, wave, bl, tile_x0, tile_y0);
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        const int len = (int)L.cnt[g1];
-        int nmax = len;
-        nmax = max(nmax, __shfl_xor(nmax, 16, 64));
-        nmax = max(nmax, __shfl_xor(nmax, 32, 64));
-        nmax = __builtin_amdgcn_readfirstlane(nmax);
-        const int lastb = (int)min(last, (uint32_t)(base + BK)) - base;          // entries of this batch below the pixel's last contributor
-        uint32_t p = (uint32_t)len * 4u + (uint32_t)g1;                            // byte offset of the list's last element
-        uint32_t jn = lbase[p];                                                    // (32 bits behind an opaque copy: the compiler narrows the loop
-        asm("" : "+v"(jn));                                                      //  variable to a byte otherwise and re-masks it every step)
-        uint32_t jpack = 0;
-        int nslot = 0;
-#pragma unroll 1
-        for (int it = 0; it < ((dbg & 8) ? 0 : nmax); ++it) {
-            const int j = (int)jn;
-            jpack = (jpack << 8) | (uint32_t)j;                                    // (here: every use of j ahead of the next element's load)
-            const bool below_last = j < lastb;
-            const float4 ea = L.ea[j];
-            const float4 eb = L.eb[j];
-            p = __builtin_elementwise_sub_sat(p, 4u);                              // an exhausted list parks on the sentinel row
-            jn = lbase[p];
-            asm("" : "+v"(jn));
-            const float dx = ea.x - pxf, dy = ea.y - pyf;
-            const float p2 = __builtin_fmaf(eb.x * dy, dy, __builtin_fmaf(ea.w, dy, ea.z * dx) * dx);   // same expression as the forward
-            const float G = __builtin_amdgcn_exp2f(p2);
-            const float oa = eb.y * G;
-            const float alpha = fminf(DVS_ALPHA_MAX, oa);
-            const bool contrib = below_last && !(p2 > 0.f) && !(alpha < DVS_ALPHA_MIN);
-#if TR_SKIP_EMPTY_STEPS
-            if (__builtin_amdgcn_ballot_w64(contrib) == 0) continue;
-#endif
-            const float2 rg = make_float2(eb.z, eb.w);
-            const float cb = L.ec[j].x;
-            const float al = contrib ? alpha : 0.f;
-            const float inv_1ma = __builtin_amdgcn_rcpf(1.f - al);
-            T = T * inv_1ma;
-            const float w = al * T;
-            const float cd = (rg.x * dLp0 + rg.y * dLp1) + cb * dLp2;
-            const float dL_dalpha = cd * T - D * inv_1ma;
-            D = D + cd * w;
-            // DVS_GRAD_TRUE: the 0.99 clamp blocks the gradient; DVS_GRAD_LINEAGE: it passes as if alpha = opacity * G
-            const bool gate = LINEAGE ? contrib : (contrib && !(oa > DVS_ALPHA_MAX));
-            const float v5 = gate ? G * dL_dalpha : 0.f;
-            // the pair goes to slot nslot of the wave's buffer, lane-indexed: ds_write_addtid_b32 (address = M0 + offset + 4 lane) needs no
-            // address register and no vector instruction for the slot offset (the scalar unit moves the slot base into M0)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:256"
-                         : : "v"(v5), "v"(w), "s"(tb_m0 + (uint32_t)(TR_SS * 4) * (uint32_t)nslot) : "memory", "m0");
-            if (++nslot == TR_SLOTS) { flush(jpack); nslot = 0; }
-        }
-        if (nslot > 0 && !(dbg & 512)) {                    // pad the unfinished round with the dummy entry (zero pairs, sink row)   (dbg 512: timing without the padded rounds — wrong results)
-            for (; nslot < TR_SLOTS; ++nslot) {
-                float* const tbw = &s_tb[0][lane];
-                tbw[TR_SS * nslot] = 0.f; tbw[TR_SS * nslot + 64] = 0.f;
-                jpack = (jpack << 8) | (uint32_t)BK;
-            }
-            flush(jpack);
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        if (b > 0) id_stage = tr_load_id<BK>(sorted_splat, range.x + (b - 1) * BK, BK);     // the next batch's ids arrive under the publish
-        // the tile's total per touched (entry, value): ONE global atomic each — consecutive threads add consecutive floats of a row.
-        // The moment and abs-grad sums were taken over v5 = G dL/dalpha; the row contract wants them over opacity * v5.
-        for (int e = lane; e < cnt * 12; e += 64) {
-            const float val = s_tab[0][e];
-            if (val != 0.f) {
-                const int ent = e / 12, comp = e - 12 * ent;
-                const uint2 io = L.idop[b & 1][ent];
-                const float sc = (comp == 5 || (comp >= 6 && comp <= 8)) ? 1.f : __uint_as_float(io.y);
-                if (comp < 11) atomicAdd(&grow[(size_t)io.x * 12 + comp], val * sc);
-                s_tab[0][e] = 0.f;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-    }
-}
-
-#endif   // TR_AUTONOMOUS
-
 // ---- launcher -------------------------------------------------------------------------------------------
 hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                     const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T,
@@ -749,18 +434,6 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
         if (absgrad) { if (lineage) DVS_TR(true, true, BKV); else DVS_TR(true, false, BKV); }           \
         else { if (lineage) DVS_TR(false, true, BKV); else DVS_TR(false, false, BKV); }                 \
     } while (0)
-#if TR_AUTONOMOUS
-    {
-        const int gridq = (((num_tiles + 7) >> 3) << 3) * 4;
-#define DVS_TRQ(A, LN) hipLaunchKernelGGL((k_render_bwd_trq<A, LN, 64>), dim3(gridq), dim3(64), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, \
-                                          num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, dbg, live_splat, live_pos)
-        if (absgrad) { if (lineage) DVS_TRQ(true, true); else DVS_TRQ(true, false); }
-        else { if (lineage) DVS_TRQ(false, true); else DVS_TRQ(false, false); }
-#undef DVS_TRQ
-        (void)grid; (void)extra_lds;
-        return hipGetLastError();
-    }
-#endif
     DVS_TR_B(64);
 #ifdef TR_STATS
     {
