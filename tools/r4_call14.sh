@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 export DVS_RASTER_LIB=$PWD/tools/xlib/lib_exp.so
-for X in 0 6000 14000 0; do
+for X in 0 4000 6000 14000 0; do
 env DVS_BWD_EXTRA_LDS=$X timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-iters 3 2>/dev/null | python -c "
 import sys, json
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
