@@ -698,8 +698,8 @@ k_tile_ranges(uint64_t T_host, const uint64_t* __restrict__ T_dev, const uint32_
 }
 
 hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles, const uint64_t* T_dev,
-                                  uint64_t T_expected) {
-    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st);
+                                  uint64_t T_expected, bool clear) {
+    hipError_t e = clear ? hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st) : hipSuccess;
     if (e != hipSuccess) return e;
     if (T == 0) return hipSuccess;
     const uint64_t T_grid = (T_dev && T_expected > 0 && T_expected < T) ? T_expected : T;

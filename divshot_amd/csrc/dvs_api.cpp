@@ -76,7 +76,15 @@ struct dvs_ctx {
     uint32_t* live_pos = nullptr;
     bool live_lists = true;              // env DVS_LIVE_LISTS=0: A8 walks the full lists (A/B and parity of the two routes)
     Buf sort_scratch, tmp_keys, tmp_vals;
-    Buf ranges, final_T, n_contrib;
+    Buf ranges, final_T, n_contrib;      // `ranges` starts with the front end's zeroed words (fe_zero_bytes), the tile ranges follow: ONE memset per forward
+    // segmented front end (frontend.hip; the default). DVS_FRONTEND=legacy selects the batch-wide sort of rounds 1-4 (binning.hip) for A/B runs.
+    bool fe_seg = true;
+    size_t fe_zero_bytes = 0;            // [kred: DVS_FE_KRED_WORDS u32][super sums: max_views x fe_nsb u64]
+    uint32_t fe_nbv = 0, fe_nsb = 0;     // A3 workgroups / super sums per view at max_splats
+    Buf fe_state;                        // [seg_all 16][seg_vis 16][seg_tile 16][superexcl V x nsb][totals V x 2048][block sums V x nbv]
+    Buf fe_hist;                         // histogram table of the segmented sorts
+    int fe_seg_n = -1, fe_seg_V = -1;    // what seg_all currently describes
+    uint32_t fe_seg_rows = 0;
     Buf g_rows;
     Buf dcolor;                          // [views, n, 3] per-view colour gradients of a batched A9 when the caller gives no buffer
     uint64_t* total_dev = nullptr;       // [0] = T of the last forward, [1] = number of forwards whose T exceeded the instance capacity
@@ -140,6 +148,26 @@ void timing_collect(dvs_ctx* c, bool append) {
     }
 }
 
+uint32_t* ranges_ptr(dvs_ctx* c) { return (uint32_t*)((char*)c->ranges.p + c->fe_zero_bytes); }
+uint32_t* fe_kred(dvs_ctx* c) { return (uint32_t*)c->ranges.p; }
+unsigned long long* fe_super(dvs_ctx* c) { return (unsigned long long*)((char*)c->ranges.p + (size_t)DVS_FE_KRED_WORDS * 4); }
+DvsSeg* fe_seg_all(dvs_ctx* c) { return c->fe_state.as<DvsSeg>(); }
+DvsSeg* fe_seg_vis(dvs_ctx* c) { return c->fe_state.as<DvsSeg>() + DVS_MAX_VIEWS; }
+DvsSeg* fe_seg_tile(dvs_ctx* c) { return c->fe_state.as<DvsSeg>() + 2 * DVS_MAX_VIEWS; }
+uint32_t* fe_superexcl(dvs_ctx* c) { return (uint32_t*)(c->fe_state.as<DvsSeg>() + 3 * DVS_MAX_VIEWS); }
+uint32_t* fe_totals(dvs_ctx* c) { return fe_superexcl(c) + (size_t)c->max_views * c->fe_nsb; }
+uint32_t* fe_block_sums(dvs_ctx* c) { return fe_totals(c) + (size_t)c->max_views * DVS_FE_MAXBINS; }
+int ensure_frontend_arenas(dvs_ctx* c) {
+    dvs_fe_block_counts((int)c->max_splats, &c->fe_nbv, &c->fe_nsb);
+    c->fe_zero_bytes = (size_t)DVS_FE_KRED_WORDS * 4 + (size_t)c->max_views * c->fe_nsb * 8 * DVS_FE_SUPER_STRIDE;
+    c->fe_zero_bytes = (c->fe_zero_bytes + 255) & ~(size_t)255;
+    int r;
+    const size_t state = 3 * DVS_MAX_VIEWS * sizeof(DvsSeg) + ((size_t)c->max_views * c->fe_nsb + (size_t)c->max_views * DVS_FE_MAXBINS + (size_t)c->max_views * c->fe_nbv) * 4;
+    if ((r = c->fe_state.ensure(state)) != DVS_OK) return r;
+    if ((r = c->fe_hist.ensure(dvs_fe_hist_words((uint64_t)c->max_splats * c->max_views, c->max_views, DVS_FE_MAXBINS) * 4)) != DVS_OK) return r;
+    return DVS_OK;
+}
+
 int ensure_splat_arenas(dvs_ctx* c, size_t n) {
     int r;
 #define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
@@ -155,7 +183,7 @@ int ensure_image_arenas(dvs_ctx* c, int w, int h, int views) {
     const size_t P = (size_t)w * h * views;
     const size_t tiles = (size_t)((w + DVS_TILE - 1) / DVS_TILE) * ((h + DVS_TILE - 1) / DVS_TILE) * views;
     int r;
-    if ((r = c->ranges.ensure(tiles * 8)) != DVS_OK) return r;
+    if ((r = c->ranges.ensure(c->fe_zero_bytes + tiles * 8)) != DVS_OK) return r;
     if ((r = c->final_T.ensure(P * 4)) != DVS_OK) return r;
     if ((r = c->n_contrib.ensure(P * 4)) != DVS_OK) return r;
     return DVS_OK;
@@ -174,6 +202,7 @@ int ensure_instance_arenas(dvs_ctx* c, uint64_t T) {
     }
     if (c->inst_cap >= (1ull << 32)) c->inst_cap = (1ull << 32) - 1;       // instance offsets are 32-bit
     if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(c->inst_cap) * 4)) != DVS_OK) return r;      // async: grids are sized for the capacity
+    if ((r = c->fe_hist.ensure(dvs_fe_hist_words(c->inst_cap, c->max_views, 512) * 4)) != DVS_OK) return r;
     return DVS_OK;
 }
 }  // namespace
@@ -194,9 +223,12 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
     if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e, __FILE__, __LINE__); return nullptr; }
     dvs_ctx* c = new dvs_ctx();
     c->device = device; c->max_splats = max_splats; c->max_w = max_w; c->max_h = max_h; c->max_views = max_views;
-    if (const char* v = getenv("DVS_BWD_VARIANT"))
+    // (A/B runs; the retired kernels exist in experiment builds only — elsewhere the request falls back to the default)
+    if (const char* v = getenv("DVS_BWD_VARIANT")) {
         c->bwd_variant = v[0] == '0' ? DVS_BWD_BLOCKS : v[0] == '1' ? DVS_BWD_REDUCE : v[0] == '2' ? DVS_BWD_MM : DVS_BWD_TR;
-    if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = v[0] == '0' ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
+        if ((c->bwd_variant == DVS_BWD_REDUCE || c->bwd_variant == DVS_BWD_MM) && !dvs_launch_render_bwd) c->bwd_variant = DVS_BWD_TR;
+    }
+    if (const char* v = getenv("DVS_FWD_VARIANT")) c->fwd_variant = (v[0] == '0' && dvs_launch_render_fwd_blocks) ? DVS_FWD_BLOCKS : DVS_FWD_QUADRANT;
     if (const char* v = getenv("DVS_LIVE_LISTS")) c->live_lists = v[0] != '0';
     if (hipMalloc((void**)&c->total_dev, 32) != hipSuccess || hipHostMalloc((void**)&c->total_host, 32, hipHostMallocDefault) != hipSuccess ||
         hipMemset(c->total_dev, 0, 32) != hipSuccess) {
@@ -206,7 +238,9 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
     }
     c->total_host[0] = c->total_host[1] = c->total_host[2] = c->total_host[3] = 0;   // [0] T  [1] arena overflows  [2] broken look-back chains (chained-scan sort)
     if (const char* v = getenv("DVS_ASYNC")) c->async_T = v[0] == '1';
-    if (ensure_splat_arenas(c, max_splats * (size_t)max_views) != DVS_OK || ensure_image_arenas(c, max_w, max_h, max_views) != DVS_OK ||
+    if (const char* v = getenv("DVS_FRONTEND")) c->fe_seg = !(v[0] == 'l' || v[0] == '0');
+    if (ensure_frontend_arenas(c) != DVS_OK ||
+        ensure_splat_arenas(c, max_splats * (size_t)max_views) != DVS_OK || ensure_image_arenas(c, max_w, max_h, max_views) != DVS_OK ||
         ensure_instance_arenas(c, (uint64_t)max_splats * 4 * (uint64_t)max_views) != DVS_OK) {
         dvs_destroy(c);
         return nullptr;
@@ -220,7 +254,7 @@ void dvs_destroy(dvs_ctx* c) {
     (void)hipSetDevice(c->device);
     Buf* all[] = {&c->radii, &c->splat2d, &c->depth, &c->flags, &c->tiles_touched, &c->rect, &c->rect_sorted, &c->key[0], &c->key[1],
                   &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
-                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows, &c->dcolor};
+                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows, &c->dcolor, &c->fe_state, &c->fe_hist};
     for (Buf* b : all) b->release();
     if (c->total_dev) (void)hipFree(c->total_dev);
     if (c->total_host) (void)hipHostFree(c->total_host);
@@ -247,22 +281,10 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     StageTimer tm(c, st);
     const int tight = opts->tile_bounds == DVS_TILES_TIGHT ? 1 : 0;      // opt-in: only the tiles the alpha >= 1/255 ellipse reaches (dvs_raster.h)
 
-    // A2 preprocess: one lane per splat, all views
-    size_t e0 = tm.mark();
-    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
-                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
-                                       c->depth.as<float>(),
-                                       c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
-                                       c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>(), tight ? c->rect.as<uint32_t>() : nullptr));
-    size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
-    // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
-    int cur = 0;
-    HIPCHECK(dvs_launch_sort(st, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
-                             (uint64_t)nV, 0, 32, c->sort_scratch.as<uint32_t>(), nullptr, 0, (unsigned long long*)(c->total_dev + 2), &cur));
-    size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
-    // A3 scan in depth order (the one random gather of the binning stage: the tile rectangles)
     uint64_t T = 0, T_expected = 0;
     const uint64_t* T_dev = nullptr;           // async: the kernels over instances read T on the device, grids sized for the capacity
+    int icur = 0;
+    size_t e7 = 0;
     if (c->async_T) {
         // No host synchronisation: the arenas are over-allocated, T stays on the device. What the host knows is the T of EARLIER
         // forwards on this context (pinned copy, refreshed asynchronously): it grows the arenas ahead of need and reports an overflow
@@ -292,6 +314,84 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         T_dev = c->total_dev;
         T_expected = lastT > 0 ? lastT + lastT / 16 + 4096 : 0;      // grid size only: the kernels stride over whatever T turns out to be
     }
+    if (c->fe_seg) {
+        // ---- the segmented front end (frontend.hip): every view is a segment of the sorts, workgroup b works for view b % V ----
+        const int rect_fmt = tight ? DVS_FE_RECT_TIGHT : (tiles_x <= 255 && tiles_y <= 255) ? DVS_FE_RECT_U8 : DVS_FE_RECT_U16;
+        // one memset: the key-range slots and super sums of the front end + the tile ranges behind them
+        HIPCHECK(hipMemsetAsync(c->ranges.p, 0, c->fe_zero_bytes + (size_t)tiles * V * 8, st));
+        size_t e0 = tm.mark();
+        HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
+                                           opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
+                                           c->depth.as<float>(), c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
+                                           nullptr, opts->shn_layout, rect_fmt == DVS_FE_RECT_U16 ? c->rect.as<uint32_t>() : nullptr,
+                                           rect_fmt == DVS_FE_RECT_TIGHT ? c->rect.as<uint32_t>() : nullptr,
+                                           rect_fmt == DVS_FE_RECT_U8 ? c->rect.as<uint32_t>() : nullptr, fe_kred(c)));
+        size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
+        if (n > 0) {
+            // A5 (low 32 key bits): three range-adaptive passes per view; the culled splats leave in the first
+            const uint32_t rows = dvs_depth_sort_rows_per_view(n, V);
+            if (c->fe_seg_n != n || c->fe_seg_V != V || c->fe_seg_rows != rows) {
+                HIPCHECK(dvs_launch_seg_init(st, n, V, rows, fe_seg_all(c)));
+                c->fe_seg_n = n; c->fe_seg_V = V; c->fe_seg_rows = rows;
+            }
+            HIPCHECK(dvs_launch_depth_sort(st, n, V, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
+                                           fe_seg_all(c), fe_seg_vis(c), fe_kred(c), c->fe_hist.as<uint32_t>(), fe_totals(c)));
+        }
+        size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
+        // A3: tile counts in depth order (the one random gather: the tile rectangles), the views' instance ranges; T stays on the device
+        const uint64_t lastT = c->total_host[0];
+        const uint64_t t_hint = T_expected ? T_expected : (lastT ? lastT : (uint64_t)nV * 3);
+        const uint32_t tile_part = dvs_fe_part_for(t_hint);
+        if (n > 0)
+            HIPCHECK(dvs_launch_seg_binning(st, n, V, rect_fmt, fe_seg_vis(c), fe_seg_tile(c), c->ids[1].as<uint32_t>(), c->rect.as<uint32_t>(),
+                                            c->rect_sorted.as<uint32_t>(), fe_block_sums(c), fe_super(c), fe_superexcl(c), tile_part,
+                                            (unsigned long long*)c->total_dev, c->async_T ? c->inst_cap : ~0ull, 0, tiles_x, nullptr, nullptr));
+        else
+            HIPCHECK(hipMemsetAsync(c->total_dev, 0, 8, st));
+        HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 32, hipMemcpyDeviceToHost, st));
+        size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
+        if (!c->async_T) {
+            HIPCHECK(hipStreamSynchronize(st));
+            T = c->total_host[0];
+            if (T >= (1ull << 32)) { g_last_error = "dvs_raster_forward: more than 2^32 tile instances"; return DVS_ERR_CAPACITY; }
+            { int r = ensure_instance_arenas(c, T ? T : 1); if (r != DVS_OK) return r; }
+        }
+        // A4 duplicate, view by view
+        size_t e4 = tm.mark();
+        if (n > 0)
+            HIPCHECK(dvs_launch_seg_binning(st, n, V, rect_fmt, fe_seg_vis(c), fe_seg_tile(c), c->ids[1].as<uint32_t>(), c->rect.as<uint32_t>(),
+                                            c->rect_sorted.as<uint32_t>(), fe_block_sums(c), fe_super(c), fe_superexcl(c), tile_part,
+                                            (unsigned long long*)c->total_dev, c->inst_cap, 1, tiles_x, c->inst_tile[0].as<uint32_t>(),
+                                            c->inst_splat[0].as<uint32_t>()));
+        size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
+        // A5 (high key bits): every view's instances by tile id; the last pass hands out view * tiles + tile
+        if (n > 0) {
+            const uint64_t cap = c->async_T ? c->inst_cap : T;
+            const uint32_t nbtot = (uint32_t)(cap / tile_part) + (uint32_t)V + 2u;
+            HIPCHECK(dvs_launch_seg_sort(st, V, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
+                                         c->inst_splat[1].as<uint32_t>(), fe_seg_tile(c), 0, tiles > 1 ? bits_for((uint32_t)(tiles - 1)) : 1,
+                                         c->async_T ? (T_expected ? T_expected : c->inst_cap) : T, tile_part, nbtot, c->fe_hist.as<uint32_t>(), fe_totals(c),
+                                         (uint32_t)tiles, &icur));
+        }
+        size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
+        // A6 ranges (cleared by the memset above)
+        HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), ranges_ptr(c), tiles * V, T_dev, T_expected, false));
+        e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
+    } else {
+    // A2 preprocess: one lane per splat, all views
+    size_t e0 = tm.mark();
+    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
+                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
+                                       c->depth.as<float>(),
+                                       c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
+                                       c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>(), tight ? c->rect.as<uint32_t>() : nullptr));
+    size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
+    // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
+    int cur = 0;
+    HIPCHECK(dvs_launch_sort(st, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
+                             (uint64_t)nV, 0, 32, c->sort_scratch.as<uint32_t>(), nullptr, 0, (unsigned long long*)(c->total_dev + 2), &cur));
+    size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
+    // A3 scan in depth order (the one random gather of the binning stage: the tile rectangles)
     HIPCHECK(dvs_launch_tile_scan(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
                                   c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull, tight));
     HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 32, hipMemcpyDeviceToHost, st));
@@ -309,15 +409,15 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
                                   tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap, n, V, tiles, tight));
     size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
     // A5 (high key bits): sort by (view, tile) over the instances
-    int icur = 0;
     const int tile_bits = bits_for((uint32_t)(tiles * V - 1));
     HIPCHECK(dvs_launch_sort(st, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
                              c->inst_splat[1].as<uint32_t>(), T, 0, tile_bits, c->sort_scratch.as<uint32_t>(), T_dev, T_expected,
                              (unsigned long long*)(c->total_dev + 2), &icur));
     size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
     // A6 ranges
-    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), c->ranges.as<uint32_t>(), tiles * V, T_dev, T_expected));
-    size_t e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
+    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), ranges_ptr(c), tiles * V, T_dev, T_expected));
+    e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
+    }
     // A7 composite
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
     // the live lists of A7 (entries that reach their tile, compacted) go into the sort's other pair of instance arrays, free by now
@@ -333,11 +433,11 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         // sort's ping-pong buffers is RESERVED for them until the next forward on this context: nothing after the sort may reuse
         // inst_*[icur ^ 1].
         if (c->live_lists && c->bwd_variant == DVS_BWD_TR) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
-        HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+        HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, ranges_ptr(c), c->inst_splat[icur].as<uint32_t>(),
                                        c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>(),
                                        c->live_splat, c->live_pos, rec_masks, rec_cap));
     } else
-        HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, c->ranges.as<uint32_t>(), c->inst_splat[icur].as<uint32_t>(),
+        HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, ranges_ptr(c), c->inst_splat[icur].as<uint32_t>(),
                                               c->splat2d.as<float>(), cam->bg, out_rgb,
                                               c->final_T.as<float>(), c->n_contrib.as<uint32_t>()));
     if (c->probe) (void)probe_event(c, st);
@@ -348,7 +448,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     s.flags = c->flags.as<uint32_t>();
     s.tiles_touched = c->tiles_touched.as<uint32_t>();
     s.sorted_tile = c->inst_tile[icur].as<uint32_t>(); s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
-    s.ranges = c->ranges.as<uint32_t>(); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
+    s.ranges = ranges_ptr(c); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
     s.num_rendered = c->async_T ? DVS_T_UNKNOWN : T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y;
     s._pad = 0;
     c->n_views = V;
@@ -426,10 +526,12 @@ static int bwd_composite(dvs_ctx* c, hipStream_t st, const dvs_camera* cams, con
     else if (c->bwd_variant == DVS_BWD_BLOCKS)
         HIPCHECK(dvs_launch_render_bwd_blocks(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d,
                                               bgs, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode));
-    else
+    else {                                                 // experiment builds: the retired kernels (the mm experiment renders one view)
+        if (!dvs_launch_render_bwd) { g_last_error = "dvs_raster_backward: this build does not contain the selected composite-backward variant"; return DVS_ERR_INVALID; }
         HIPCHECK(dvs_launch_render_bwd(st, s.width, s.height, s.tiles_x, s.tiles_y, V, s.ranges, s.sorted_splat, s.splat2d,
                                        bgs, s.final_T, s.n_contrib, dL_drgb, c->g_rows.as<float>(), opts->absgrad, opts->grad_mode,
                                        V > 1 ? DVS_BWD_REDUCE : c->bwd_variant));
+    }
     if (c->probe) (void)probe_event(c, st);
     if (tm) { size_t e2 = tm->mark(); tm->span("render_bwd", e1, e2); }
     c->rows_pending = true;
@@ -599,6 +701,15 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
     uint32_t* k[2] = {keys, c->tmp_keys.as<uint32_t>()};
     uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
     int cur = 0;
+    if (c->fe_seg) {
+        if (n >= (1ull << 32)) { g_last_error = "dvs_sort_pairs_u32: n must be below 2^32"; return DVS_ERR_CAPACITY; }
+        if ((r = c->fe_hist.ensure(dvs_fe_hist_words(n, 1, 512) * 4)) != DVS_OK) return r;
+        const uint32_t part = dvs_fe_part_for(n);
+        HIPCHECK(dvs_launch_seg_init(st, (int)n, 1, 0, fe_seg_all(c)));      // one segment: [0, n)
+        c->fe_seg_n = -1;                                                    // (the forward's descriptors are gone)
+        HIPCHECK(dvs_launch_seg_sort(st, 1, k[0], v[0], k[1], v[1], fe_seg_all(c), bit_lo, bit_hi - bit_lo, n, part, (uint32_t)(n / part) + 3u,
+                                     c->fe_hist.as<uint32_t>(), fe_totals(c), 0u, &cur));
+    } else
     HIPCHECK(dvs_launch_sort(st, k[0], v[0], k[1], v[1], n, bit_lo, bit_hi, c->sort_scratch.as<uint32_t>(), nullptr, 0,
                              (unsigned long long*)(c->total_dev + 2), &cur));
     if (cur == 1) {
@@ -679,6 +790,11 @@ int dvs_debug_record_decisions(dvs_ctx* c, uint64_t* take_masks, uint64_t capaci
 
 int dvs_set_backward_variant(dvs_ctx* c, int variant) {
     if (!c || variant < DVS_BWD_BLOCKS || variant > DVS_BWD_TR) { g_last_error = "dvs_set_backward_variant: bad argument"; return DVS_ERR_INVALID; }
+    if ((variant == DVS_BWD_REDUCE || variant == DVS_BWD_MM) && !dvs_launch_render_bwd) {
+        g_last_error = "dvs_set_backward_variant: the 'reduce' and 'mm' kernels are retired — this library contains 'tr' (default) and 'blocks' only "
+                       "(an experiment build, tools/xbuild.sh, brings them back)";
+        return DVS_ERR_UNSUPPORTED;
+    }
     c->bwd_variant = variant;
     return DVS_OK;
 }
@@ -689,6 +805,10 @@ int dvs_set_live_lists(dvs_ctx* c, int enable) {
 }
 int dvs_set_forward_variant(dvs_ctx* c, int variant) {
     if (!c || (variant != DVS_FWD_BLOCKS && variant != DVS_FWD_QUADRANT)) { g_last_error = "dvs_set_forward_variant: bad argument"; return DVS_ERR_INVALID; }
+    if (variant == DVS_FWD_BLOCKS && !dvs_launch_render_fwd_blocks) {
+        g_last_error = "dvs_set_forward_variant: the per-block forward is retired — this library contains the quadrant forward only (tools/xbuild.sh brings it back)";
+        return DVS_ERR_UNSUPPORTED;
+    }
     c->fwd_variant = variant;
     return DVS_OK;
 }

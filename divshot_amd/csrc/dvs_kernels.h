@@ -10,7 +10,9 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii /*per-view outputs are [n_views][n]*/, float* splat2d,
                                      float* depth, uint32_t* flags,
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect /*[n,2]: 4 x u16*/,
-                                     uint32_t* rect16 /*DVS_TILES_TIGHT: [n,4] = rectangle + 64-bit tile mask, written instead of rect; null = canonical*/);
+                                     uint32_t* rect16 /*DVS_TILES_TIGHT: [n,4] = rectangle + 64-bit tile mask, written instead of rect; null = canonical*/,
+                                     uint32_t* rect8 = nullptr /*DVS_FE_RECT_U8: [n] 4 x u8 (minx, miny, width, height) instead of rect*/,
+                                     uint32_t* kred = nullptr /*segmented front end: the views' key ranges [n_views][64][16] (zeroed by the caller); ids may then be null*/);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,
@@ -31,6 +33,40 @@ hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, i
 // reference rows [n][45] <-> tiled [ceil(n/64)][45][64]
 hipError_t dvs_launch_dcolor_from_rows(hipStream_t st, int64_t total, const int* radii, const uint32_t* flags, const float* rows, float* dcolor);
 hipError_t dvs_launch_shn_relayout(hipStream_t st, int n, const float* src, float* dst, int to_tiled);
+
+// frontend.hip — the segmented (per-view) binning stage of round 5
+// One segment of a segmented sort / scan (device memory, 32 B): a view's run of elements and its rows of the histogram table.
+struct DvsSeg {
+    uint32_t base;      // first element of the segment in the key / value arrays
+    uint32_t count;     // its elements
+    uint32_t pstart;    // its first row (partition) in the histogram table
+    uint32_t sub;       // depth sort: the view's smallest key (digits are taken from key - sub)
+    uint32_t bits;      // depth sort: digit width b = ceil(bits(max - min) / 3), 1..11
+    uint32_t _r0, _r1, _r2;
+};
+// tile-rectangle record formats (A2 writes, A3 gathers, A4 streams)
+enum { DVS_FE_RECT_U8 = 0 /*4 B: minx | miny << 8 | width << 16 | height << 24 (tiles_x, tiles_y <= 255)*/, DVS_FE_RECT_U16 = 1 /*8 B: 4 x u16*/,
+       DVS_FE_RECT_TIGHT = 2 /*16 B: 4 x u16 + the 64-bit tile mask of DVS_TILES_TIGHT*/ };
+#define DVS_FE_KRED_WORDS (DVS_MAX_VIEWS * 64 * 16)        /* key-range slots: [view][64][16 words] */
+#define DVS_FE_MAXBINS 2048
+#define DVS_FE_SUPER_STRIDE 32                                  /* u64 words between two super-sum counters (256 B: own memory channel) */
+size_t dvs_fe_hist_words(uint64_t max_elems, int n_views, int max_bins);       // histogram table words for sorts of up to max_elems elements in n_views segments
+uint32_t dvs_depth_sort_rows_per_view(int n, int V);
+uint32_t dvs_fe_part_for(uint64_t grid_elems);                                 // keys per partition for a sort of about that many elements
+void dvs_fe_block_counts(int n, uint32_t* nbv, uint32_t* nsb);                 // A3 workgroups per view, 64-bit super sums per view
+hipError_t dvs_launch_seg_init(hipStream_t st, int n, int V, uint32_t rows_per_view, DvsSeg* seg_all);
+// A5 (depth): keys0 [V][n] (culled = 0xFFFFFFFF) -> vals1[v * n + j] = index of the j-th nearest visible splat of view v, j < seg_vis[v].count
+hipError_t dvs_launch_depth_sort(hipStream_t st, int n, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
+                                 DvsSeg* seg_all, DvsSeg* seg_vis, const uint32_t* kred, uint32_t* hist, uint32_t* totals /*[V][DVS_FE_MAXBINS]*/);
+// stable LSD sort of every segment's pairs over the key bits [bit_lo, bit_lo + bits) (digits <= 9 bits); result in buffers *result_in
+hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
+                               uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
+                               int* result_in);
+// stage 0 = A3 (tile counts in depth order, block / super sums) + the views' instance ranges (seg_tile, total_dev); stage 1 = A4
+hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, const DvsSeg* seg_vis, DvsSeg* seg_tile, const uint32_t* sorted_ids,
+                                  const uint32_t* rect, uint32_t* rect_sorted, uint32_t* block_sums, unsigned long long* super, uint32_t* superexcl,
+                                  uint32_t tile_part, unsigned long long* total_dev, unsigned long long capacity, int stage, int tiles_x,
+                                  uint32_t* inst_tile, uint32_t* inst_splat);
 
 // binning.hip
 // Number of uint32 scratch words dvs_launch_sort needs for up to n items.
@@ -58,7 +94,7 @@ hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_id
                                 int n_per_view, int n_views, int tiles_per_view, int tight);
 // A6: per-tile [start,end) from the sorted tile ids. T_dev (nullable): device-side count, T sizes the grid.
 hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles,
-                                  const uint64_t* T_dev = nullptr, uint64_t T_expected = 0);
+                                  const uint64_t* T_dev = nullptr, uint64_t T_expected = 0, bool clear = true /*false: the caller has zeroed `ranges`*/);
 // canonical 64-bit keys of the sorted list (parity export)
 hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, const uint32_t* sorted_splat,
                                   const float* depth, uint64_t* out_keys);
@@ -71,17 +107,20 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
                                  position -> number of such entries before it in its tile*/,
                                  uint64_t* take_masks /*test hook (or null): [take_cap][4] zeroed by the caller — per list position and 8x8 quadrant, the pixels that took the entry*/,
                                  uint64_t take_cap);
+// EXPERIMENT BUILDS ONLY (-DDVS_EXPERIMENT): the retired A8 kernels "reduce" and "mm". Declared weak: the release library does not
+// define it, dvs_set_backward_variant refuses those variants there.
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows /*[n,12] zero-initialised*/, int absgrad, int grad_mode,
-                                 int variant /*DVS_BWD_*: which A8 kernel (the mm experiment renders one view)*/);
+                                 int variant /*DVS_BWD_*: which A8 kernel (the mm experiment renders one view)*/) __attribute__((weak));
 // A8 kernel variants (dvs_set_backward_variant): same inputs, same 48-B row contract, results equal to fp32 roundoff
-enum { DVS_BWD_BLOCKS = 0 /*per-4x4-block lists, four cursors per wave, 12-value group reduction per step (round 2)*/, DVS_BWD_REDUCE = 1 /*per-quadrant
-       masks, wave-wide reduction tree per visit (round 1)*/, DVS_BWD_MM = 2 /*per-quadrant masks, sums contracted on the fp32 matrix pipe (experiment)*/,
+enum { DVS_BWD_BLOCKS = 0 /*per-4x4-block lists, four cursors per wave, 12-value group reduction per step (round 2): kept in the release library as
+       the independent-summation-order cross-check of the parity tests*/, DVS_BWD_REDUCE = 1 /*per-quadrant masks, wave-wide reduction tree per visit
+       (round 1; experiment builds only)*/, DVS_BWD_MM = 2 /*per-quadrant masks, sums contracted on the fp32 matrix pipe (experiment builds only)*/,
        DVS_BWD_TR = 3 /*per-4x4-block lists; (v5, w) pairs transposed through LDS and accumulated serially per (block, slot, pixel row):
        render_tr.hip (default since round 3)*/ };
 // A7 kernel variants (dvs_set_forward_variant): bit-identical results
-enum { DVS_FWD_BLOCKS = 0 /*per-4x4-block lists (experiment)*/, DVS_FWD_QUADRANT = 1 /*per-quadrant masks walked by the scalar unit (default)*/ };
+enum { DVS_FWD_BLOCKS = 0 /*per-4x4-block lists (experiment builds only)*/, DVS_FWD_QUADRANT = 1 /*per-quadrant masks walked by the scalar unit (default)*/ };
 
 // render_tr.hip
 hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
@@ -93,7 +132,7 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
 // render_blocks.hip
 hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                         const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color,
-                                        float* final_T, uint32_t* n_contrib);
+                                        float* final_T, uint32_t* n_contrib) __attribute__((weak));      // experiment builds only
 hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                         const uint32_t* sorted_splat, const float* splat2d, const float* bgs /*[n_views][3]*/, const float* final_T,
                                         const uint32_t* n_contrib, const float* dL_dout, float* grad_rows, int absgrad, int grad_mode);

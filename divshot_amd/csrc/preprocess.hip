@@ -77,7 +77,10 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
                  uint32_t* __restrict__ flags,
                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
                  uint2* __restrict__ rect /*tile rectangle [minx | maxx << 16, miny | maxy << 16]; empty for culled splats*/,
-                 uint4* __restrict__ rect16 /*DVS_TILES_TIGHT: {rectangle, tile mask lo, hi} instead of `rect` (null: canonical rectangles)*/) {
+                 uint4* __restrict__ rect16 /*DVS_TILES_TIGHT: {rectangle, tile mask lo, hi} instead of `rect` (null: canonical rectangles)*/,
+                 uint32_t* __restrict__ rect8 /*DVS_FE_RECT_U8: minx | miny << 8 | width << 16 | height << 24 instead of `rect` (null: 16-bit fields)*/,
+                 uint32_t* __restrict__ kred /*segmented front end (frontend.hip): [view][64 slots][16 words], word 0 = max(~key), word 1 = max(key)
+                 over the view's visible splats, zeroed by the caller; null = the batch-wide sort of rounds 1-4, which wants `ids`*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] when deg>0
     const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
@@ -277,9 +280,26 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     flags[o] = out_flags;
     tiles_touched[o] = out_tiles;
     if (rect16) rect16[o] = make_uint4(out_rect.x, out_rect.y, (uint32_t)out_mask, (uint32_t)(out_mask >> 32));
-    else rect[o] = out_rect;
+    else if (rect8) {
+        const uint32_t x0 = out_rect.x & 0xFFFFu, y0 = out_rect.y & 0xFFFFu;
+        rect8[o] = x0 | (y0 << 8) | (((out_rect.x >> 16) - x0) << 16) | (((out_rect.y >> 16) - y0) << 24);
+    } else rect[o] = out_rect;
     depth_key[o] = out_key;
-    ids[o] = (uint32_t)o;
+    if (ids) ids[o] = (uint32_t)o;
+    if (kred) {
+        // the view's key range for the range-adaptive depth sort: one pair of atomics per wave into one of 64 slots (64 B apart)
+        uint32_t knm = ~out_key, kmx = out_radius > 0 ? out_key : 0u;         // both are max reductions with identity 0 (culled: ~0xFFFFFFFF = 0)
+        uint32_t* slot = kred + ((size_t)view * 64 + (blockIdx.x & 63u)) * 16;
+        if (wave_base + 64 <= n) {
+            // wave64 max in six DPP steps (row_shr 1, 2, 4, 8, row_bcast 15, 31): lane 63 ends with the wave's maximum
+#define A2_DPP_MAX(v, ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false); v = o_ > v ? o_ : v; }
+            A2_DPP_MAX(knm, 0x111, 0xF) A2_DPP_MAX(kmx, 0x111, 0xF) A2_DPP_MAX(knm, 0x112, 0xF) A2_DPP_MAX(kmx, 0x112, 0xF)
+            A2_DPP_MAX(knm, 0x114, 0xF) A2_DPP_MAX(kmx, 0x114, 0xF) A2_DPP_MAX(knm, 0x118, 0xF) A2_DPP_MAX(kmx, 0x118, 0xF)
+            A2_DPP_MAX(knm, 0x142, 0xA) A2_DPP_MAX(kmx, 0x142, 0xA) A2_DPP_MAX(knm, 0x143, 0xC) A2_DPP_MAX(kmx, 0x143, 0xC)
+#undef A2_DPP_MAX
+            if ((threadIdx.x & 63) == 63 && knm != 0u) { atomicMax(slot, knm); atomicMax(slot + 1, kmx); }
+        } else if (out_radius > 0) { atomicMax(slot, knm); atomicMax(slot + 1, kmx); }
+    }
     }   // views
 }
 
@@ -880,13 +900,14 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      const float* opacity, const float* scale, const float* rot, const DvsCams& cams, int n_views,
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
                                      float* depth, uint32_t* flags,
-                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect, uint32_t* rect16) {
+                                     uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect, uint32_t* rect16,
+                                     uint32_t* rect8, uint32_t* kred) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
     if (shn_tiled) {
 #define DVS_A2(T, M, LDS) hipLaunchKernelGGL((k_preprocess_fwd<T, M>), dim3(grid), dim3(PP_BLOCK), LDS, st, cams, n_views, n, pos, sh0, shN, opacity, \
                                              scale, rot, deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,          \
-                                             tiles_touched, depth_key, ids, (uint2*)rect, (uint4*)rect16)
+                                             tiles_touched, depth_key, ids, (uint2*)rect, (uint4*)rect16, rect8, kred)
         if (n_views > 1) DVS_A2(true, true, 0); else DVS_A2(true, false, 0);
     } else {
         const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;

@@ -138,11 +138,11 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
              float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
              uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
              uint32_t* __restrict__ live_pos /*[T] per list position: how many entries before it (in its tile) reach the tile*/,
-             int dbg_arg /*experiment builds: 1 = stage the batches but skip the walk (timing only)*/,
-             uint64_t* __restrict__ take_masks /*RECORD: [capacity][4], zeroed by the caller*/, uint64_t take_cap) {
+             uint64_t* __restrict__ take_masks /*RECORD: [capacity][4], zeroed by the caller*/, uint64_t take_cap
+             DVS_DBG_PARAM /*experiment builds: 1 = stage the batches but skip the walk*/) {
     __shared__ FwdLds L;
     (void)bg_arg;
-    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;
+    const int dbg = DVS_DBG_VALUE;
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
     if (tile_g >= num_tiles) return;
     const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
@@ -275,6 +275,11 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
     }
 }
 
+// ---- A8, retired kernels: experiment builds only (-DDVS_EXPERIMENT, tools/xbuild.sh) ---------------------------------------------
+// "reduce" (round 1) and "mm" (the matrix-pipe experiment of round 2) are 40-90 % slower than the shipped kernel (render_tr.hip) and are
+// not part of libdvsraster.so: dvs_set_backward_variant refuses them there. They stay in the source as the measured alternatives of
+// DESIGN.md §5; an experiment build brings them back for A/B runs (DVS_TEST_ALL_VARIANTS=1 with DVS_RASTER_LIB=tools/xlib/...).
+#ifdef DVS_EXPERIMENT
 // ---- A8 -------------------------------------------------------------------------------------------
 template <bool ABSGRAD>
 __global__ void __launch_bounds__(RB)
@@ -424,7 +429,7 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
                 const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d, float bg0, float bg1, float bg2,
                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout,
                 float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int lineage, int dbg_arg /*experiment builds: ablation bits*/) {
-    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;
+    const int dbg = dbg_arg;
     __shared__ BatchLds L;
     __shared__ uint32_t s_max[RB / 64];
     __shared__ __attribute__((aligned(16))) float2 s_pair[RB / 64][MM_SLOTS * MM_STRIDE];   // per wave: [slot][pixel] (v5, w); epilogue scratch
@@ -612,6 +617,8 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
     }
 }
 
+#endif  // DVS_EXPERIMENT
+
 // ---- launchers -----------------------------------------------------------------------------------------
 
 hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
@@ -620,16 +627,19 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
+#ifdef DVS_EXPERIMENT
     static const int dbg = dvs_experiment_int("DVS_FWD_DEBUG");
+#endif
     if (take_masks)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, dbg, take_masks, take_cap);
+                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, take_masks, take_cap DVS_DBG_PASS(dbg));
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, dbg, nullptr, 0);
+                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, (uint64_t*)nullptr, (uint64_t)0 DVS_DBG_PASS(dbg));
     return hipGetLastError();
 }
 
+#ifdef DVS_EXPERIMENT
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T, const uint32_t* n_contrib,
                                  const float* dL_dout, float* grad_rows, int absgrad, int grad_mode, int variant) {
@@ -655,3 +665,4 @@ hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int 
     }
     return hipGetLastError();
 }
+#endif  // DVS_EXPERIMENT

@@ -172,6 +172,8 @@ __device__ __forceinline__ int wave_max4(int v) {
     return max(max(a, b), max(c, d));
 }
 
+// (the per-block forward is an experiment of round 2 — same image bits as k_render_fwd, not faster: experiment builds only)
+#ifdef DVS_EXPERIMENT
 // ---- A7 -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RB)
 k_render_fwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __restrict__ ranges,
@@ -240,6 +242,8 @@ k_render_fwd_blocks(int W, int H, int tiles_x, int num_tiles, const uint2* __res
 // 12 per-lane partials -> per-GROUP totals (group = lanes with equal lane & 3). As wave_reduce12 (render_common.h) but the
 // butterfly stops after the column bits 2 and 3: q[k] holds, in lane (row r, column c), the total over the lanes of group c & 3 of
 // value index  q[0]: v0,v2,v1,v3   q[1]: v4,v6,v5,v7   q[2]: v8,v10,v9,v11  (by row r).
+#endif  // DVS_EXPERIMENT
+
 template <int NV>
 __device__ __forceinline__ void group_reduce12(const float v[12], float q[3], int xaddr) {
     const float h0 = swap32_add(v[0], v[1]), h1 = swap32_add(v[2], v[3]), h2 = swap32_add(v[4], v[5]);
@@ -396,6 +400,7 @@ k_render_bwd_blocks(ViewBg bg_arg /* MUST stay the first parameter: read through
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
+#ifdef DVS_EXPERIMENT
 hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, const uint32_t* ranges,
                                         const uint32_t* sorted_splat, const float* splat2d, const float bg[3], float* out_color,
                                         float* final_T, uint32_t* n_contrib) {
@@ -406,6 +411,7 @@ hipError_t dvs_launch_render_fwd_blocks(hipStream_t st, int W, int H, int tiles_
                        (const float4*)splat2d, bg[0], bg[1], bg[2], out_color, final_T, n_contrib);
     return hipGetLastError();
 }
+#endif  // DVS_EXPERIMENT
 
 hipError_t dvs_launch_render_bwd_blocks(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                         const uint32_t* sorted_splat, const float* splat2d, const float* bgs, const float* final_T,

@@ -10,8 +10,14 @@
 // (tests/test_abi.py::test_release_build_has_no_ablation_knobs). DVS_EXPERIMENT_ON folds the knob tests away at compile time.
 #ifdef DVS_EXPERIMENT
 #define DVS_EXPERIMENT_ON 1
+#define DVS_DBG_PARAM , int dbg_arg /*experiment builds: ablation bits (timing only)*/
+#define DVS_DBG_PASS(x) , (x)
+#define DVS_DBG_VALUE dbg_arg
 #else
 #define DVS_EXPERIMENT_ON 0
+#define DVS_DBG_PARAM              /* release kernels and helpers have no ablation argument at all */
+#define DVS_DBG_PASS(x)
+#define DVS_DBG_VALUE 0
 #endif
 
 // Experiment knob of the occupancy measurements (tools/bwd_probe.py): DVS_BWD_EXTRA_LDS = bytes of dynamic LDS added to the composite

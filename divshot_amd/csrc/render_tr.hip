@@ -78,7 +78,8 @@ __device__ __forceinline__ uint32_t tr_load_id(const uint32_t* __restrict__ sort
 // holding one block sit in one wave (BK = 64) or one half wave (BK = 32), so ranks and lengths come straight from that wave's ballots.
 template <int BK>
 __device__ __forceinline__ void tr_stage(TrLds<BK>& L, const float4* __restrict__ splat2d, uint32_t id, int cnt, int base, int parity,
-                                         float tile_x0, float tile_y0, int dbg = 0) {
+                                         float tile_x0, float tile_y0 DVS_DBG_PARAM) {
+    const int dbg = DVS_DBG_VALUE;
     constexpr int GPT = 16 * BK / RB;
     static_assert(GPT == 4 || GPT == 2, "BK must be 64 or 32");
     const int t = threadIdx.x, e = t % BK, sub = t / BK, lane = t & 63;
@@ -148,14 +149,14 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
                 int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
                 const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dout /*[views,3,H,W]*/,
-                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/, int dbg_arg /*experiment builds: ablation bits (timing only)*/,
+                float* __restrict__ grow /*[n,12], same row contract as k_render_bwd*/ DVS_DBG_PARAM,
                 const uint32_t* __restrict__ live_splat /*k_render_fwd's compacted lists (entries that reach the tile), or null*/,
                 const uint32_t* __restrict__ live_pos /*list position -> position in the compacted list*/) {
     __shared__ TrLds<BK> L;
     __shared__ float s_tab[4][(BK + 1) * 12];               // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
     __shared__ __attribute__((aligned(16))) float s_tb[4][TR_SLOTS * TR_SS];  // per wave: slot, plane (v5 | w), phase-1 lane
     (void)bg_arg;
-    const int dbg = DVS_EXPERIMENT_ON ? dbg_arg : 0;       // release builds: every `dbg &` test below folds away
+    const int dbg = DVS_DBG_VALUE;                          // release builds: 0, every `dbg &` test below folds away
     const int tile_g = tile_of_block(blockIdx.x, num_tiles);
     if (tile_g >= num_tiles) return;
     const int view = tile_g / tiles_per_view, tile = tile_g - view * tiles_per_view;
@@ -320,7 +321,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
         const int base = b * BK;
         const int cnt = min(BK, (int)todo - base);
         // (no barrier here: the publish of batch b + 1, which other threads may still be in, reads the tables and idop[(b + 1) & 1] only)
-        tr_stage<BK>(L, splat2d, id_stage, cnt, base, b & 1, tile_x0, tile_y0, dbg);
+        tr_stage<BK>(L, splat2d, id_stage, cnt, base, b & 1, tile_x0, tile_y0 DVS_DBG_PASS(dbg));
         if (!(dbg & 256)) __syncthreads();                  // batch staged; the tables are zero again        (dbg 256: timing of a barrier-free batch loop — wrong results)
         const int len = (int)L.cnt[blk1];
         int nmax = len;
@@ -424,11 +425,13 @@ hipError_t dvs_launch_render_bwd_tr(hipStream_t st, int W, int H, int tiles_x, i
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
     const int lineage = grad_mode == 1 ? 1 : 0;
+#ifdef DVS_EXPERIMENT
     static const int dbg = dvs_experiment_int("DVS_TR_DEBUG");      // ablation bits of tools/bwd_probe.py (timing only; experiment builds)
+#endif
     const size_t extra_lds = dvs_experiment_extra_lds();
 #define DVS_TR(A, LN, BKV)                                                                                                          \
     hipLaunchKernelGGL((k_render_bwd_tr<A, LN, BKV>), dim3(grid), dim3(RB), extra_lds, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, \
-                       num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows, dbg, live_splat, live_pos)
+                       num_tiles, (const uint2*)ranges, sorted_splat, (const float4*)splat2d, final_T, n_contrib, dL_dout, grad_rows DVS_DBG_PASS(dbg), live_splat, live_pos)
 #define DVS_TR_B(BKV)                                                                                   \
     do {                                                                                                \
         if (absgrad) { if (lineage) DVS_TR(true, true, BKV); else DVS_TR(true, false, BKV); }           \

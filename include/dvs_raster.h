@@ -45,7 +45,8 @@ enum {
     DVS_ERR_INVALID = 1,       /* bad argument */
     DVS_ERR_HIP = 2,           /* a HIP runtime call failed; see dvs_last_error() */
     DVS_ERR_CAPACITY = 3,      /* n > max_splats or image > max_w x max_h given to dvs_create */
-    DVS_ERR_STATE = 4          /* backward called without a matching forward */
+    DVS_ERR_STATE = 4,         /* backward called without a matching forward */
+    DVS_ERR_UNSUPPORTED = 5    /* the library was built without what was asked for (a retired kernel variant) */
 };
 
 /* A0 — splat parameter block. DEVICE pointers, SoA, raw (pre-activation) fp32.
@@ -261,18 +262,20 @@ int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
  * is held to the 1e-4 bar (tests/test_gpu_parity.py). Same arithmetic and images as without it; NULL switches it off. */
 int dvs_debug_record_decisions(dvs_ctx* ctx, uint64_t* take_masks, uint64_t capacity_instances);
 
-/* The composite kernels exist in several variants with the same inputs and outputs, kept selectable so that the measured
- * comparison can be repeated (all of them pass the same parity tests). Backward (A8), results equal to fp32 roundoff:
+/* The library ships ONE composite forward (A7, "quadrant") and ONE composite backward (A8, "tr"), plus the round-2 backward "blocks" as
+ * the independent-summation-order cross-check of the parity tests. The other measured alternatives of DESIGN.md §5 — backward "reduce"
+ * (round 1) and "mm" (matrix-pipe experiment), forward "blocks" — are retired: their source stays in csrc/ behind -DDVS_EXPERIMENT
+ * (tools/xbuild.sh builds such a library for A/B runs) and the release library answers DVS_ERR_UNSUPPORTED when they are asked for.
+ * Backward (A8), results equal to fp32 roundoff:
  *   3 "tr"      (default since round 3) per-4x4-pixel-block splat lists; a list step ends when the pair's two per-pixel scalars
  *               (G dL/dalpha, alpha T) are known: they cross an LDS transposition buffer, and every four steps each lane sums one
  *               pixel row of one (block, step) pair serially in registers (moments about the row origin moved to the mean
  *               algebraically) — no cross-lane reduction per step; per-wave LDS tables, one global atomic per (tile, splat, value)
  *   0 "blocks"  (round 2) the same lists; a 12-value reduction over the block's 16 lanes per step, group totals into the per-wave table
- *   1 "reduce"  (round 1) per-8x8-quadrant cull masks, a 12-value wave-wide reduction tree and one atomic row update per (wave, splat) visit
- *   2 "mm"      per-quadrant masks, the per-splat sums contracted on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); bound by its
- *               LDS footprint (3 workgroups per CU) and by the matrix and vector pipes not overlapping; one view per launch only
- * Forward (A7), bit-identical results:  1 "quadrant" (default) / 0 "blocks".
- * The environment variables DVS_BWD_VARIANT / DVS_FWD_VARIANT (digits) set the defaults of new contexts. */
+ *   1 "reduce"  (retired) per-8x8-quadrant cull masks, a 12-value wave-wide reduction tree and one atomic row update per (wave, splat) visit
+ *   2 "mm"      (retired) per-quadrant masks, the per-splat sums contracted on the fp32 matrix pipe; one view per launch only
+ * Forward (A7), bit-identical results:  1 "quadrant" (default) / 0 "blocks" (retired).
+ * The environment variables DVS_BWD_VARIANT / DVS_FWD_VARIANT (digits) set the defaults of new contexts (a retired variant is ignored). */
 int dvs_set_backward_variant(dvs_ctx* ctx, int variant);
 int dvs_set_forward_variant(dvs_ctx* ctx, int variant);
 /* Live lists (default on; DVS_LIVE_LISTS=0 sets the default of new contexts off): the "quadrant" forward writes, per tile, the

@@ -99,3 +99,34 @@ def test_release_build_has_no_ablation_knobs():
         for k in knobs:
             assert k not in blob, f"{os.path.basename(path)} still carries the experiment knob {k.decode()}"
     assert os.environ.get("DVS_RASTER_LIB") or os.path.basename(_lib.LIB_PATH) == "libdvsraster.so"
+
+
+def test_release_build_ships_one_forward_and_one_backward_kernel():
+    """libdvsraster.so contains the composite forward (k_render_fwd), the composite backward (k_render_bwd_tr) and the
+    round-2 backward kept as the parity tests' cross-check (k_render_bwd_blocks) — none of the retired kernels ("reduce" = k_render_bwd,
+    "mm", the per-block forward), neither as host stubs nor as device code."""
+    if os.environ.get("DVS_RASTER_LIB"):
+        return                                              # an experiment library is allowed to carry them
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for retired in (b"k_render_bwd_mm", b"k_render_fwd_blocks", b"12k_render_bwdILb"):       # (Itanium mangling: <length><name>I...)
+        assert retired not in blob, f"libdvsraster.so still contains the retired kernel {retired.decode()}"
+    for shipped in (b"12k_render_fwdILb", b"15k_render_bwd_trILb", b"19k_render_bwd_blocksILb"):
+        assert shipped in blob, shipped
+
+
+def test_retired_variants_are_refused():
+    """dvs_set_backward_variant / dvs_set_forward_variant answer DVS_ERR_UNSUPPORTED for kernels the library does not contain (needs a device
+    for the context; on CPU the symbols and the error code are checked)."""
+    import torch
+    assert hasattr(dv.lib, "dvs_set_backward_variant") and hasattr(dv.lib, "dvs_set_forward_variant")
+    if not torch.cuda.is_available() or os.environ.get("DVS_RASTER_LIB"):
+        return
+    ctx = dv.lib.dvs_create(0, 1024, 64, 64)
+    assert ctx
+    try:
+        assert dv.lib.dvs_set_backward_variant(ctx, 1) == 5 and dv.lib.dvs_set_backward_variant(ctx, 2) == 5      # reduce, mm: DVS_ERR_UNSUPPORTED
+        assert b"retired" in dv.lib.dvs_last_error()
+        assert dv.lib.dvs_set_forward_variant(ctx, 0) == 5
+        assert dv.lib.dvs_set_backward_variant(ctx, 0) == 0 and dv.lib.dvs_set_backward_variant(ctx, 3) == 0 and dv.lib.dvs_set_forward_variant(ctx, 1) == 0
+    finally:
+        dv.lib.dvs_destroy(ctx)

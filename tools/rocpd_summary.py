@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 rocpd SQLite database (`rocprofv3 --kernel-trace --stats -d DIR -o NAME`) into the
 per-kernel table committed under profiles/: calls, total/avg/min/max duration (us), share of GPU time, launch shape
 and register use. Optionally PMC counter sums per kernel when the db came from a --pmc pass.
-usage: tools/rocpd_summary.py results.db > profiles/rNN_kernel_stats.txt"""
+usage: tools/rocpd_summary.py results.db [--by-grid] > profiles/rNN_kernel_stats.txt"""
 import re
 import sqlite3
 import sys
@@ -15,10 +15,12 @@ def short(name):
 
 def main():
     db = sys.argv[1]
+    by_grid = "--by-grid" in sys.argv[2:]          # one row per (kernel, launch grid): separates the passes of a sort that share a kernel
     c = sqlite3.connect(db)
     rows = c.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(grid_x), max(workgroup_x), "
-        "max(lds_size), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count) from kernels group by name order by sum(duration) desc").fetchall()
+        "max(lds_size), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count) from kernels group by name" + (", grid_x" if by_grid else "") +
+        " order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     print(f"# rocprofv3 kernel-trace summary of {db}")
     print(f"# {'kernel':52s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s} {'grid':>9s} {'wg':>5s} {'lds':>6s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s}")
