@@ -132,6 +132,30 @@ def cpu_baseline(workload, max_seconds=60.0):
 cpu_baseline.reference = None
 
 
+def scaling_model(n, world, views_per_rank, per_rank_compute_ms, measured_ms_per_step):
+    """DESIGN.md §7's model of the data-parallel step, evaluated beside the measurement so that a scaling run tests a prediction:
+    step = per-rank compute + exposed exchange. Factorised exchange over point-to-point xGMI with every peer link driven at once
+    (direct reduce-scatter + all-gather): the colour all-gather moves views_per_rank * 12 B/splat per link and direction and overlaps A9
+    (taken as 0.1 ms per local view); the all-reduce of the 44 B/splat geometry prefix moves 2 * 44/world B/splat per link and direction
+    and is exposed. Assumed: 64 GB/s per link and direction achieved by RCCL, 30 us per collective. Inputs measured by this run: the
+    ranks' compute time (start of a step to just before its exposed exchange). A MODEL, stated as such; null for one GPU."""
+    if world <= 1 or not per_rank_compute_ms:
+        return None
+    bw, lat_ms = 64e9, 0.030
+    t_gather = views_per_rank * n * 12 / bw * 1e3 + lat_ms
+    t_reduce = 2 * (44 * n / world) / bw * 1e3 + lat_ms
+    a9_ms = 0.1 * views_per_rank
+    exposed = t_reduce + max(0.0, t_gather - a9_ms)
+    compute = max(per_rank_compute_ms)
+    step = compute + exposed
+    return {"assumptions": {"link_GBps_per_direction": 64, "latency_us_per_collective": 30, "a9_ms_per_local_view": 0.1,
+                            "links_driven": world - 1, "exchange": "factorised, direct reduce-scatter + all-gather on every peer link"},
+            "all_gather_ms": t_gather, "all_reduce_ms": t_reduce, "predicted_exposed_exchange_ms": exposed,
+            "measured_per_rank_compute_ms_max": compute, "predicted_ms_per_step": step,
+            "predicted_views_per_s": world * views_per_rank / (step * 1e-3),
+            "measured_ms_per_step": measured_ms_per_step, "measured_over_predicted": measured_ms_per_step / step}
+
+
 def watchdog_seconds():
     try:
         return max(30.0, float(os.environ.get("DVS_BENCH_WATCHDOG_S", "900")))
@@ -181,6 +205,12 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "factorised", "allreduce"],
                     help="N>1 gradient exchange: one all-reduce of all 236 B/splat, or factorised (all-reduce of 44 B + all-gather of "
                          "12 B per splat per view, SH rows rebuilt locally, gathers overlapped with compute); auto = factorised")
+    ap.add_argument("--exchange-impl", default="dvs_comm", choices=["dvs_comm", "torch"],
+                    help="N>1: who runs the collectives. dvs_comm (default) = the product's communication layer, include/dvs_comm.h (librccl "
+                         "behind plain C, the calls libgstrain.so's train_step makes), with its stream / event choreography: early colour "
+                         "all-gather, optionally chunked A9 with one grouped launch per chunk, SH rebuild under the geometry all-reduce; no "
+                         "torch.distributed at all (barrier and max-over-ranks go through the same communicator). torch = "
+                         "torch.distributed (backend nccl = RCCL), the path of rounds 1-4, kept for A/B")
     ap.add_argument("--global-views", type=int, default=8, help="views per training iteration, sharded over the GPUs (BASELINE config C4: 8)")
     ap.add_argument("--views-per-step", type=int, default=0,
                     help="if > 0: this many views PER GPU per step instead of sharding --global-views (weak scaling, the round-1 shape)")
@@ -249,13 +279,15 @@ def main():
         time.sleep(1e6)
     dist = None
     ndev = max(1, torch.cuda.device_count())
-    if world > ndev and os.environ.get("DVS_DIST_BACKEND", "nccl") == "nccl":
+    if world > ndev and args.exchange_impl == "torch" and os.environ.get("DVS_DIST_BACKEND", "nccl") == "nccl":
         raise SystemExit(f"bench.py: {world} ranks need {world} GPUs over RCCL, this node has {ndev} "
                          "(DVS_DIST_BACKEND=gloo lets a functional test oversubscribe one GPU)")
     dev_index = local_rank % ndev          # (a functional test may oversubscribe one GPU with a gloo group; normally 1 rank = 1 GPU)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    if world > 1 or os.environ.get("DVS_FORCE_COLLECTIVES") == "1":     # (forced: the N>1 step over a 1-rank communicator — a hardware test of the path)
+    multi = world > 1 or os.environ.get("DVS_FORCE_COLLECTIVES") == "1"     # (forced: the N>1 step over a 1-rank communicator — a hardware test of the path)
+    comm = None
+    if multi and args.exchange_impl == "torch":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -264,6 +296,30 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=watchdog_seconds()))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=watchdog_seconds()))
+    elif multi:
+        # the product's layer: librccl through include/dvs_comm.h; rank 0 serves the RCCL id on MASTER_PORT + 1789 (DVS_COMM_PORT).
+        # DVS_COMM_BACKEND=tcp (tests only: two ranks on one GPU) is announced on stderr and recorded in the line.
+        from divshot_amd.parallel import DvsComm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if world > ndev and os.environ.get("DVS_COMM_BACKEND") != "tcp":
+            raise SystemExit(f"bench.py: {world} ranks need {world} GPUs over RCCL, this node has {ndev} (DVS_COMM_BACKEND=tcp lets a functional test share one GPU)")
+        comm = DvsComm(dev_index, rank, world)
+
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+        elif dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if comm is not None:
+            return comm.max_over_ranks(x)
+        if dist is not None:
+            t_ = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        return x
 
     n, W, H, deg, soff = WORKLOADS[args.workload]
     weak = args.views_per_step > 0
@@ -326,10 +382,16 @@ def main():
         # The factorised exchange gathers the views of all but the last group under the compute of the following group:
         # (w-1) 12 G + ring 44 < ring 236 for every world size.
         exchange = "factorised"
-    factorised = dist is not None and exchange == "factorised"
+    factorised = multi and exchange == "factorised"
     early = factorised and bool(args.early_gather) and K == 1
+    if comm is not None and factorised and not early:
+        raise SystemExit("bench.py: --exchange-impl dvs_comm runs the product's choreography (--mode batch with the early gather); use --exchange-impl torch for the other modes")
     if factorised:
-        fx = FactorisedExchange(n, dev, world, views_per_rank=VPS, rank_major=early)
+        if comm is not None:
+            from divshot_amd.parallel import DvsCommExchange
+            fx = DvsCommExchange(n, dev, comm, views_per_rank=VPS)
+        else:
+            fx = FactorisedExchange(n, dev, world, views_per_rank=VPS, rank_major=early)
         dcolor_scratch = torch.empty((VPS, n, 3), dtype=torch.float32, device=dev) if early else None
         campos_all = np.array([list(dv.synth_camera(spec, views_of(r)[v]).campos) for r, v in fx.slots()], np.float32)
         # rebuild the SH rows of a view's slots right behind its all-gather, on the exchange's side stream
@@ -347,11 +409,15 @@ def main():
     step_done = torch.cuda.Event()
     main_stream = torch.cuda.current_stream(dev)
     comm_marks = []                               # (event before the exposed exchange, event after it) per timed step
+    step_marks = []                               # (event at the start of a timed step, event before its exchange): this rank's compute
     torch.cuda.synchronize()
 
     gm = {"mode": args.grad_mode}            # (mutable: the lineage-mode side measurement below re-times the same step in grad_mode 1)
 
     def step(timed=False):
+        e_start = None
+        if timed and multi:
+            e_start = torch.cuda.Event(enable_timing=True); e_start.record(main_stream)
         if n_ctx > 1:
             step_done.record(main_stream)          # everything enqueued so far (previous step incl. its exchange)
         for gi in range(K):
@@ -393,29 +459,31 @@ def main():
                         fx.gather_view(v, bwd_done[c] if n_ctx > 1 else None)      # overlaps with the next group's kernels
         if n_ctx > 1:
             main_stream.wait_event(bwd_done[(K - 1) % n_ctx])
-        if dist is not None:
+        if multi:
             ea = None
             if timed:
                 ea = torch.cuda.Event(enable_timing=True); ea.record(main_stream)
             if factorised:
                 fx.exchange(gbuf, rast, params["pos"], campos_all, deg, shn_tiled=tiled)
+            elif comm is not None:
+                comm.all_reduce_sum(flat)
             else:
                 dist.all_reduce(flat)
             if timed:
                 eb = torch.cuda.Event(enable_timing=True); eb.record(main_stream)
                 comm_marks.append((ea, eb))
+                step_marks.append((e_start, ea))
 
     # (no fallback: if the exchange cannot run on this stack the bench fails loudly instead of measuring something else)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     run_step = step
     graph = None
     if args.graph:
-        if dist is not None or n_ctx > 1 or not args.async_forward:
+        if multi or n_ctx > 1 or not args.async_forward:
             raise SystemExit("bench.py: --graph needs one GPU, one context (--mode batch) and --async-forward 1")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -433,14 +501,10 @@ def main():
         run_step(timed=True)
     marks[args.steps].record(main_stream)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     # the same step in the other gradient mode (libgstrain.so runs DVS_GRAD_LINEAGE, the headline DVS_GRAD_TRUE): a short timed
     # side loop, so that "same cost" is a measured statement
@@ -450,20 +514,14 @@ def main():
         for _ in range(5):
             step()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        barrier()
         k_other = max(5, min(50, args.steps))
         t1 = time.perf_counter()
         for _ in range(k_other):
             step()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        el = time.perf_counter() - t1
-        if dist is not None:
-            t_ = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            el = float(t_.item())
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t1)
         other_mode = {"grad_mode": gm["mode"], "steps": k_other, "views_per_s": GLOBAL_VIEWS * k_other / el, "ms_per_step": el / k_other * 1e3}
         gm["mode"] = args.grad_mode
         step(); torch.cuda.synchronize()          # leave the gradient buffer as the timed region left it (norms below)
@@ -474,29 +532,43 @@ def main():
     # rccl-tests-style microbenchmark of the collectives the exchange is made of, at the exchange's sizes; outside the
     # timed region, on scratch buffers. busbw uses the rccl-tests convention (all-reduce 2(N-1)/N, all-gather (N-1)/N of the total).
     comm_micro = None
-    if dist is not None:
+    per_rank_compute_ms = None
+    if multi:
         def _coll_ms(fn, iters=10):
             for _ in range(3):
                 fn()
-            torch.cuda.synchronize(); dist.barrier()
+            torch.cuda.synchronize(); barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
                 fn()
             e1.record(); torch.cuda.synchronize()
-            t_ = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device=dev)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            return float(t_.item())
+            return max_over_ranks(e0.elapsed_time(e1) / iters * 1e-3) * 1e3
         s_geom = torch.zeros_like(gbuf.flat_geom); s_flat = torch.zeros_like(gbuf.flat)
         s_loc = torch.zeros((VPS * n * 3,), device=dev); s_all = torch.zeros((world * VPS * n * 3,), device=dev)
+        if comm is not None:
+            f_geom, f_flat, f_gather = (lambda: comm.all_reduce_sum(s_geom)), (lambda: comm.all_reduce_sum(s_flat)), (lambda: comm.all_gather(s_loc, s_all))
+        else:
+            f_geom, f_flat, f_gather = (lambda: dist.all_reduce(s_geom)), (lambda: dist.all_reduce(s_flat)), (lambda: dist.all_gather_into_tensor(s_all, s_loc))
         comm_micro = {}
         for name, nbytes, fac, fn in (
-                ("all_reduce_geometry_44B_per_splat", s_geom.numel() * 4, 2.0 * (world - 1) / world, lambda: dist.all_reduce(s_geom)),
-                ("all_reduce_full_rows_236B_per_splat", s_flat.numel() * 4, 2.0 * (world - 1) / world, lambda: dist.all_reduce(s_flat)),
-                ("all_gather_dcolor_12B_per_splat_and_view", s_all.numel() * 4, (world - 1) / world, lambda: dist.all_gather_into_tensor(s_all, s_loc))):
+                ("all_reduce_geometry_44B_per_splat", s_geom.numel() * 4, 2.0 * (world - 1) / world, f_geom),
+                ("all_reduce_full_rows_236B_per_splat", s_flat.numel() * 4, 2.0 * (world - 1) / world, f_flat),
+                ("all_gather_dcolor_12B_per_splat_and_view", s_all.numel() * 4, (world - 1) / world, f_gather)):
             ms_ = _coll_ms(fn)
             comm_micro[name] = {"bytes": nbytes, "ms": ms_, "algbw_GBps": nbytes / ms_ / 1e6, "busbw_GBps": fac * nbytes / ms_ / 1e6}
         del s_geom, s_flat, s_loc, s_all
+        # this rank's compute per step = start of the step -> just before the exposed exchange (the early colour all-gather and, when
+        # chunked, the geometry groups already run underneath on the communication stream); gathered from every rank
+        if step_marks:
+            torch.cuda.synchronize()
+            mine = sum(a.elapsed_time(b) for a, b in step_marks) / len(step_marks)
+            if comm is not None:
+                per_rank_compute_ms = comm.gather_floats(mine)
+            else:
+                tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+                dist.all_gather(tl, torch.tensor([mine], dtype=torch.float64, device=dev))
+                per_rank_compute_ms = [float(t_.item()) for t_ in tl]
     # everything below measures ONE view at a time: its own single-view context (the step's contexts are sized and primed for groups)
     rast1 = Rasterizer(dev_index, max_splats=n, max_w=W, max_h=H)
     rast1.set_backward_variant(args.bwd_variant); rast1.set_forward_variant(args.fwd_variant); rast1.set_async(bool(args.async_forward))
@@ -537,8 +609,7 @@ def main():
                 acc_p[k_][0] += ms_ * cnt_; acc_p[k_][1] += cnt_
             r_.kernel_probe(False)
         probe = {k_: (v_[0] / v_[1] if v_[1] else None) for k_, v_ in acc_p.items()}
-        if dist is not None:
-            dist.barrier()
+        barrier()
     # ---- per-stage hipEvent timing of the STEP's own multi-view pass (one GPU, batch mode): the launches the timed region makes, with
     # stage timing on (each call then synchronises; kernel durations are unaffected) — feeds roofline.kernels[]
     batch_stage_ms = {}
@@ -564,9 +635,20 @@ def main():
                 acc.setdefault(k, []).append(v)
         rast1.enable_timing(False)
         stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
-    if dist is not None:
-        dist.barrier()
+    barrier()
 
+    exchange_info = None
+    if multi:
+        exchange_info = {
+            "impl": args.exchange_impl + (": include/dvs_comm.h, the calls of libgstrain.so's train_step" if comm is not None else ": torch.distributed"),
+            "backend": comm.backend if comm is not None else ("torch.distributed/" + dist.get_backend()),
+            # what the COMMUNICATOR itself reports (ncclCommCount through dvs_comm_backend_ranks), not the launcher's WORLD_SIZE
+            "rccl_nranks": comm.backend_ranks if comm is not None else dist.get_world_size(),
+            "world_size_env": world, "exchange": exchange, "early_gather": bool(early), "a9_chunks": len(a9_chunks) if a9_chunks else 1,
+            "choreography": ("colour all-gather on the communication stream behind dvs_raster_backward_dcolor (under A9); "
+                             + ("A9 in %d splat chunks, each chunk's geometry groups as ONE grouped launch behind it; " % len(a9_chunks) if a9_chunks else "geometry all-reduce behind A9; ")
+                             + "SH rows rebuilt on the compute stream when the gather has landed, under the geometry all-reduce") if factorised else "one all-reduce of the flat gradient buffer",
+        }
     if rank == 0:
         st = rast1.state
         V = int((torch.from_numpy(rast1._d2h(st.radii, (n,), np.int32)) > 0).sum())
@@ -722,6 +804,8 @@ def main():
             "other_grad_mode": other_mode,
             "strict_single_view": strict, "t_raster_ms_per_step": (ms_per_step - comm_ms["mean"]) if comm_ms else ms_per_step,
             "t_comm_exposed_ms_per_step": comm_ms, "comm_microbench": comm_micro, "clocks": clocks,
+            "exchange": exchange_info, "rccl_nranks": exchange_info["rccl_nranks"] if exchange_info else None,
+            "per_rank_compute_ms": per_rank_compute_ms, "scaling_model": scaling_model(n, world, VPS, per_rank_compute_ms, ms_per_step),
             "step_ms_p10_p50_p90": step_spread,
             "device": device_info,
             "dtype": "f32", "data": "synthetic",
@@ -789,9 +873,11 @@ def main():
     rast1.close()
     for r_ in rasts:
         r_.close()
+    barrier()
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
     if watchdog is not None:
         watchdog.cancel()
 

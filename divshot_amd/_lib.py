@@ -110,6 +110,8 @@ _PROTOS = {
     "dvs_comm_destroy": (None, [C.c_void_p]),
     "dvs_comm_rank": (C.c_int, [C.c_void_p]),
     "dvs_comm_world": (C.c_int, [C.c_void_p]),
+    "dvs_comm_backend_ranks": (C.c_int, [C.c_void_p]),
+    "dvs_comm_backend_name": (C.c_char_p, [C.c_void_p]),
     "dvs_comm_all_reduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dvs_comm_all_reduce_max_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dvs_comm_reduce_scatter_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

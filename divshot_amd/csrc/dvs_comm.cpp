@@ -43,6 +43,7 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // (optional: what the COMMUNICATOR says its size is)
     bool load(std::string& err) {
         if (handle) return true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -55,6 +56,7 @@ struct Rccl {
         SYM(GetErrorString, "ncclGetErrorString") SYM(AllReduce, "ncclAllReduce") SYM(ReduceScatter, "ncclReduceScatter")
         SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
+        CommCount = (decltype(CommCount))dlsym(handle, "ncclCommCount");
         return true;
     }
 };
@@ -71,8 +73,9 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 // Bootstrap of the RCCL unique id over TCP. Rank 0 listens on the bootstrap port; every other rank connects (retrying while rank 0 is
-// not up yet), introduces itself with {magic, job nonce, rank}, gets {magic, id} back and acknowledges it. Rank 0 counts a rank once
-// (on its acknowledgement; a rank whose receive timed out may ask again while the listener is open) and keeps accepting until all
+// not up yet), introduces itself with {magic, job nonce, rank}, gets {magic, id} back, acknowledges it and waits for rank 0's one-byte
+// confirmation (a peer whose acknowledgement rank 0 failed to receive must not proceed as if it had been counted). Rank 0
+// counts a rank once (when the confirmation is out; a rank that timed out on any step asks again while the listener is open) and keeps accepting until all
 // world-1 distinct ranks have acknowledged: a stray or stale connection (wrong magic / nonce / rank, or one that sends nothing) is
 // dropped without using up a slot, a hello with our magic but the wrong nonce is logged. Every socket operation has a timeout and the whole exchange a deadline
 // (DVS_COMM_TIMEOUT_S, default 180 s), after which it fails with an error instead of hanging.
@@ -126,8 +129,10 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
                 // A rank that was served already may ask again (its 5 s receive can time out after our send_all returned): answer it
                 // again — it only counts once.
                 Reply r{}; r.magic = kMagic; memcpy(r.id, id128, 128);
-                uint32_t ack = 0;                              // the peer confirms it holds the id: only then does its slot count
-                if (send_all(fd, &r, sizeof r) && recv_all(fd, &ack, sizeof ack) && ack == kMagic) {
+                uint32_t ack = 0;                              // the peer confirms it holds the id, we confirm that its slot counts: only
+                const uint8_t confirm = 1;                     // a peer that has read this last byte returns "ok" — if our receive of the ack
+                                                               // fails the byte is never sent, the peer times out on it and asks again
+                if (send_all(fd, &r, sizeof r) && recv_all(fd, &ack, sizeof ack) && ack == kMagic && send_all(fd, &confirm, 1)) {
                     if (!served[h.rank]) { served[h.rank] = true; --left; }
                     if (keep_fds) { int& slot = (*keep_fds)[h.rank]; if (slot >= 0) ::close(slot); slot = fd; kept = true; }
                 }
@@ -153,7 +158,10 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
                 Hello h{}; h.magic = kMagic; h.rank = (uint32_t)rank; h.nonce = nonce;
                 Reply r{};
                 const uint32_t ack = kMagic;
-                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic && send_all(fd, &ack, sizeof ack)) { memcpy(id128, r.id, 128); ok = true; }
+                uint8_t confirm = 0;                           // three-way: hello -> id -> ack -> confirm. Without the confirm rank 0 has not counted us
+                                                               // (its receive of the ack failed): ask again instead of walking into ncclCommInitRank alone
+                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic && send_all(fd, &ack, sizeof ack) &&
+                    recv_all(fd, &confirm, 1) && confirm == 1) { memcpy(id128, r.id, 128); ok = true; }
             }
             if (ok && keep_fds) { (*keep_fds)[0] = fd; continue; }
             ::close(fd);
@@ -325,6 +333,14 @@ void dvs_comm_destroy(dvs_comm* c) {
 }
 int dvs_comm_rank(const dvs_comm* c) { return c ? c->rank : 0; }
 int dvs_comm_world(const dvs_comm* c) { return c ? c->world : 1; }
+int dvs_comm_backend_ranks(const dvs_comm* c) {
+    if (!c) return 0;
+    if (c->tcp) { int n = 1; for (int fd : c->fds) n += fd >= 0 ? 1 : 0; return c->rank == 0 ? n : c->world; }      // (rank 0 counts its open peer sockets)
+    int n = 0;
+    if (c->comm && g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) == 0) return n;
+    return -1;
+}
+const char* dvs_comm_backend_name(const dvs_comm* c) { return !c ? "none" : c->tcp ? "tcp (host-staged TEST backend)" : "rccl"; }
 
 int dvs_comm_all_reduce_sum_f32(dvs_comm* c, void* stream, float* buf, size_t count) {
     if (!c || (count && !buf)) { dvs_set_last_error("dvs_comm_all_reduce_sum_f32: null argument"); return DVS_ERR_INVALID; }

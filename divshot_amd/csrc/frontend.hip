@@ -173,7 +173,7 @@ template <int ITEMS> struct FeScatterLds {
 };
 
 template <int ITEMS>
-__global__ void __launch_bounds__(FE_BLOCK)
+__global__ void __launch_bounds__(FE_BLOCK) __attribute__((amdgpu_waves_per_eu(4)))      // (<= 128 VGPRs: the LDS allows four workgroups per CU)
 k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /*null: the value is the element's index in its segment*/,
               uint32_t* __restrict__ keys_out /*null: the keys are not needed any more*/, uint32_t* __restrict__ vals_out,
               const DvsSeg* __restrict__ seg_in, DvsSeg* __restrict__ seg_out /*null, or where the segments of the OUTPUT are published
@@ -205,6 +205,28 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
     uint32_t* const kout = keys_out ? keys_out + S.base : nullptr;
     uint32_t* const vout = vals_out + S.base;
 
+    const uint32_t nparts = (S.count + PART - 1) / PART;
+    const uint32_t ilast = S.count - 1u;
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    // Small sorts (ITEMS = 8: fewer workgroups than the chip holds, every kernel one latency chain) request the keys of the workgroup's
+    // first partition BEFORE the digit bases are scanned: one memory round trip less in front of the ranking. Large sorts (ITEMS = 16)
+    // request them at the top of the loop: held across the scan they would cost the fourth wave per SIMD.
+    // Unconditional loads from clamped indices (a partition is never empty): no branch per load; lanes past the end are masked later.
+    constexpr bool EARLY = ITEMS <= 8;
+    auto request = [&](uint32_t p) {
+        const uint32_t i0 = p * PART + wave * (64 * ITEMS) + lane;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; key[r] = kin[idx < ilast ? idx : ilast]; }
+        if (vin) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; val[r] = vin[idx < ilast ? idx : ilast]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) val[r] = i0 + (uint32_t)r * 64;
+        }
+    };
+    if (EARLY && w < nparts) request(w);
+
     // where each digit starts in the view's output: exclusive scan of the view's digit totals. Reorder: thread t owns bins 2t, 2t + 1 and
     // keeps their bases in registers; wide: bins 8t .. 8t + 7, bases in LDS.
     uint32_t dex0 = 0, dex1 = 0;
@@ -225,9 +247,8 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
 #pragma unroll 1
             for (uint32_t k = 0; k < 8; ++k) { const uint32_t d = tid * 8u + k; dexl[d] = run; run += d < nbins ? vtot[d] : 0u; }
         }
-        if (seg_out && w == 0 && tid == 0) { DvsSeg o = S; o.count = tot; seg_out[view] = o; }
+        if (seg_out && w == 0 && tid == 0) { seg_out[view].base = S.base; seg_out[view].count = tot; seg_out[view].pstart = S.pstart; seg_out[view].sub = S.sub; seg_out[view].bits = S.bits; }
     }
-    const uint32_t nparts = (S.count + PART - 1) / PART;
     for (uint32_t p = w; p < nparts; p += gv) {
         const size_t row = (size_t)S.pstart + p;
         __syncthreads();                                                                 // (dexl written; the previous partition's stores read their LDS)
@@ -237,21 +258,10 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
             if (2u * tid < nbins) hp0 = hist[(size_t)(2u * tid) * nbtot + row];
             if (2u * tid + 1u < nbins) hp1 = hist[(size_t)(2u * tid + 1u) * nbtot + row];
         }
+        if (!EARLY) request(p);
         __syncthreads();
-        const uint32_t wb = p * PART + wave * (64 * ITEMS);
-        uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+        const uint32_t i0 = p * PART + wave * (64 * ITEMS) + lane;
         uint32_t vmask = 0u;
-        // unconditional loads from clamped indices (the partition is not empty): no branch per load; lanes past the end are masked below
-        const uint32_t i0 = wb + lane, ilast = S.count - 1u;
-#pragma unroll
-        for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; key[r] = kin[idx < ilast ? idx : ilast]; }
-        if (vin) {
-#pragma unroll
-            for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; val[r] = vin[idx < ilast ? idx : ilast]; }
-        } else {
-#pragma unroll
-            for (int r = 0; r < ITEMS; ++r) val[r] = i0 + (uint32_t)r * 64;
-        }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const bool valid = i0 + (uint32_t)r * 64 <= ilast && !(cull && key[r] == FE_CULLED);
@@ -307,6 +317,7 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
                     vout[dst] = stage_v[slot];
                 }
             }
+            if (EARLY && p + gv < nparts) request(p + gv);        // (a workgroup rarely has a second partition: the grids cover the expected counts)
         } else {
 #pragma unroll 1
             for (uint32_t k = 0; k < 8; ++k) {
@@ -328,11 +339,16 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
                     vout[dst] = val[r];
                 }
             }
+            if (EARLY && p + gv < nparts) request(p + gv);
         }
     }
 }
 
-static inline int fe_items_for(uint64_t n_total) { return n_total <= 1500000ull ? 8 : 16; }
+static inline int fe_items_for(uint64_t n_total) {
+    static const int forced = [] { const char* e = getenv("DVS_FE_ITEMS"); return e ? atoi(e) : 0; }();        // (measurement aid: 8 / 16)
+    if (forced == 8 || forced == 16) return forced;
+    return n_total <= 1500000ull ? 8 : 16;
+}
 
 size_t dvs_fe_hist_words(uint64_t max_elems, int n_views, int max_bins) {
     const uint64_t rows = (max_elems + (uint64_t)FE_BLOCK * 8 - 1) / ((uint64_t)FE_BLOCK * 8) + (uint64_t)n_views + 6;     // sized for the smaller partition
@@ -473,23 +489,38 @@ __global__ void __launch_bounds__(FE_BLOCK)
 k_seg_blocksum(int n, int V, uint32_t nbv, uint32_t nsb, const DvsSeg* __restrict__ seg_vis, const uint32_t* __restrict__ sorted_ids,
                const typename FeRect<FMT>::T* __restrict__ rect, typename FeRect<FMT>::T* __restrict__ rect_sorted,
                uint32_t* __restrict__ block_sums, unsigned long long* __restrict__ super) {
-    __shared__ uint32_t tmp[FE_WAVES];
-    const uint32_t view = blockIdx.x % (uint32_t)V, blk = blockIdx.x / (uint32_t)V;
+    // a workgroup takes FOUR consecutive blocks of 256 elements (four independent id -> rectangle gathers in flight per thread)
+    __shared__ uint32_t wsum[4][FE_WAVES];
+    const uint32_t view = blockIdx.x % (uint32_t)V, blk0 = (blockIdx.x / (uint32_t)V) * 4u;
     const uint32_t nvis = seg_vis[view].count;
-    const uint32_t j = blk * FE_BLOCK + threadIdx.x;
-    if (blk * FE_BLOCK >= nvis) return;                       // (uniform; A4 never reads the sums of blocks behind the visible splats)
-    uint32_t v = 0;
-    if (j < nvis) {
-        const size_t o = (size_t)view * n;
-        const typename FeRect<FMT>::T r = rect[o + sorted_ids[o + j]];
-        rect_sorted[o + j] = r;
-        v = FeRect<FMT>::count(r);
+    if (blk0 * FE_BLOCK >= nvis) return;                      // (uniform; A4 never reads the sums of blocks behind the visible splats)
+    const size_t o = (size_t)view * n;
+    const uint32_t lane = fe_lane(), wave = threadIdx.x >> 6;
+    uint32_t id[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t j = (blk0 + (uint32_t)k) * FE_BLOCK + threadIdx.x; id[k] = j < nvis ? sorted_ids[o + j] : 0u; }
+    typename FeRect<FMT>::T r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = rect[o + id[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t j = (blk0 + (uint32_t)k) * FE_BLOCK + threadIdx.x;
+        uint32_t v = 0;
+        if (j < nvis) { rect_sorted[o + j] = r[k]; v = FeRect<FMT>::count(r[k]); }
+        const uint32_t s = fe_wave_sum(v);
+        if (lane == 0) wsum[k][wave] = s;
     }
-    uint32_t tot;
-    (void)fe_block_excl_scan(v, tmp, &tot);
-    if (threadIdx.x == 0) {
-        block_sums[(size_t)view * nbv + blk] = tot;
-        if (tot) atomicAdd(&super[((size_t)view * nsb + (blk >> 8)) * DVS_FE_SUPER_STRIDE], (unsigned long long)tot);       // one counter per 256 B: 256 workgroups each, the counters in parallel
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t k = threadIdx.x, blk = blk0 + k;
+        uint32_t tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < FE_WAVES; ++wv) tot += wsum[k][wv];
+        if (blk < nbv) block_sums[(size_t)view * nbv + blk] = tot;             // (blocks behind the visible splats get 0)
+        // the four blocks lie in one super block (256 blocks): one 64-bit atomic per workgroup; one counter per 256 B, so that the
+        // counters of a view are served in parallel
+        const uint32_t t4 = tot + (uint32_t)__shfl_down(tot, 1, 64) + (uint32_t)__shfl_down(tot, 2, 64) + (uint32_t)__shfl_down(tot, 3, 64);
+        if (k == 0 && t4) atomicAdd(&super[((size_t)view * nsb + (blk0 >> 8)) * DVS_FE_SUPER_STRIDE], (unsigned long long)t4);
     }
 }
 
@@ -620,9 +651,9 @@ hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, co
                                   int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat) {
     if (n <= 0 || V <= 0) return hipSuccess;
     const uint32_t nbv = (uint32_t)((n + FE_BLOCK - 1) / FE_BLOCK), nsb = (nbv + 255u) / 256u;
-    const dim3 grid(nbv * (uint32_t)V), blk(FE_BLOCK);
+    const dim3 grid(nbv * (uint32_t)V), grid3(((nbv + 3u) / 4u) * (uint32_t)V), blk(FE_BLOCK);
     if (stage == 0) {
-#define FE_A3(F) hipLaunchKernelGGL(k_seg_blocksum<F>, grid, blk, 0, st, n, V, nbv, nsb, seg_vis, sorted_ids, (const FeRect<F>::T*)rect, (FeRect<F>::T*)rect_sorted, block_sums, super)
+#define FE_A3(F) hipLaunchKernelGGL(k_seg_blocksum<F>, grid3, blk, 0, st, n, V, nbv, nsb, seg_vis, sorted_ids, (const FeRect<F>::T*)rect, (FeRect<F>::T*)rect_sorted, block_sums, super)
         if (rect_fmt == DVS_FE_RECT_U8) FE_A3(DVS_FE_RECT_U8); else if (rect_fmt == DVS_FE_RECT_U16) FE_A3(DVS_FE_RECT_U16); else FE_A3(DVS_FE_RECT_TIGHT);
 #undef FE_A3
         hipLaunchKernelGGL(k_seg_totals, dim3(1), dim3(1024), 0, st, V, nsb, (const unsigned long long*)super, superexcl, seg_tile, tile_part, total_dev, capacity);

@@ -313,3 +313,133 @@ class ShardedAdam:
             torch.cat(parts, out=dst)
         if self._ppad is not None:
             self.p.copy_(self._ppad[:n])
+
+
+# ---- the product's exchange: include/dvs_comm.h (librccl behind plain C), driven with the plugin's stream / event choreography ---------
+class DvsComm:
+    """ctypes handle of a dvs_comm communicator (include/dvs_comm.h): the SAME C entry points libgstrain.so's train_step() calls
+    (divshot_amd/gstrain/gstrain.cpp) — RCCL over xGMI, or, with DVS_COMM_BACKEND=tcp, the host-staged test backend. rank / world /
+    rendezvous come from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) unless given."""
+
+    def __init__(self, device_index, rank=-1, world=0, master_addr=None, master_port=0):
+        from ._lib import lib, DvsError
+        self._lib = lib
+        self.h = lib.dvs_comm_create(int(device_index), int(rank), int(world), master_addr.encode() if master_addr else None, int(master_port))
+        if not self.h:
+            raise DvsError("dvs_comm_create failed: " + lib.dvs_last_error().decode())
+        self.rank, self.world = lib.dvs_comm_rank(self.h), lib.dvs_comm_world(self.h)
+        self.backend = lib.dvs_comm_backend_name(self.h).decode()
+        self.backend_ranks = lib.dvs_comm_backend_ranks(self.h)        # what RCCL itself reports (ncclCommCount)
+        self.dev = torch.device("cuda", device_index)
+        self._scratch_i = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self._scratch_f = torch.zeros(max(4, self.world), dtype=torch.float32, device=self.dev)
+
+    def close(self):
+        if self.h:
+            self._lib.dvs_comm_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def _sp(stream):
+        import ctypes as C
+        return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def _ok(self, status, what):
+        if status != 0:
+            from ._lib import DvsError
+            raise DvsError(f"{what} failed with status {status}: {self._lib.dvs_last_error().decode()}")
+
+    def all_reduce_sum(self, t, stream=None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._ok(self._lib.dvs_comm_all_reduce_sum_f32(self.h, self._sp(stream), t.data_ptr(), t.numel()), "dvs_comm_all_reduce_sum_f32")
+
+    def all_gather(self, send, recv, stream=None):
+        assert send.is_cuda and recv.is_cuda and send.dtype == recv.dtype == torch.float32 and recv.numel() == send.numel() * self.world
+        self._ok(self._lib.dvs_comm_all_gather_f32(self.h, self._sp(stream), send.data_ptr(), recv.data_ptr(), send.numel()), "dvs_comm_all_gather_f32")
+
+    def group_start(self):
+        self._ok(self._lib.dvs_comm_group_start(self.h), "dvs_comm_group_start")
+
+    def group_end(self):
+        self._ok(self._lib.dvs_comm_group_end(self.h), "dvs_comm_group_end")
+
+    # host-visible helpers of a benchmark (each synchronises the current stream)
+    def barrier(self):
+        self._ok(self._lib.dvs_comm_all_reduce_max_i32(self.h, self._sp(None), self._scratch_i.data_ptr(), 1), "dvs_comm_all_reduce_max_i32")
+        torch.cuda.current_stream().synchronize()
+
+    def max_over_ranks(self, seconds):
+        """max of a host float over the ranks (as integer microseconds through the int32 max-all-reduce)."""
+        self._scratch_i[0] = int(min(2 ** 31 - 1, round(seconds * 1e6)))
+        self._ok(self._lib.dvs_comm_all_reduce_max_i32(self.h, self._sp(None), self._scratch_i.data_ptr(), 1), "dvs_comm_all_reduce_max_i32")
+        torch.cuda.current_stream().synchronize()
+        return int(self._scratch_i[0].item()) * 1e-6
+
+    def gather_floats(self, value):
+        """[value of rank 0, ..., value of rank world - 1] on every rank."""
+        send = torch.full((1,), float(value), dtype=torch.float32, device=self.dev)
+        recv = self._scratch_f[: self.world]
+        self.all_gather(send, recv)
+        torch.cuda.current_stream().synchronize()
+        return [float(x) for x in recv.cpu()]
+
+
+class DvsCommExchange:
+    """The factorised exchange of FactorisedExchange, executed by the PRODUCT's communication layer with the product's choreography
+    (gstrain.cpp train_step): every collective goes through include/dvs_comm.h on a dedicated communication stream,
+    in the same order on every rank —
+      * the colour gradients of all local views leave in ONE all-gather as soon as dvs_raster_backward_dcolor has produced them
+        (under A9),
+      * A9 may run in splat chunks; chunk k's 44 B/splat of geometry gradients (four ranges of the flat buffer) leave as ONE grouped
+        launch behind its event, under the A9 of the chunks behind it; otherwise one all-reduce of the geometry prefix behind A9,
+      * the SH rows are rebuilt on the compute stream as soon as the all-gather has landed — while the geometry all-reduce is still
+        on the links — and the step ends when that has landed too.
+    Same attribute / method names as FactorisedExchange's rank-major form, so bench.py's step drives either (--exchange-impl)."""
+    rank_major = True
+
+    def __init__(self, n, device, comm, views_per_rank=1):
+        self.n, self.comm, self.world, self.views_per_rank = n, comm, comm.world, views_per_rank
+        self.dcolor_local = torch.zeros((views_per_rank, n, 3), dtype=torch.float32, device=device)
+        self.dcolor_all = torch.zeros((self.world * views_per_rank, n, 3), dtype=torch.float32, device=device)
+        self._comm = torch.cuda.Stream(device=device)
+        self._ev_gather, self._ev_bwd, self._ev_comm = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self._gathered = False
+        self._geom_reduced = False
+
+    def slots(self):
+        return [(r, v) for r in range(self.world) for v in range(self.views_per_rank)]
+
+    def gather_all(self, ready=None, group=None):
+        if ready is not None:
+            self._comm.wait_event(ready)
+        else:
+            self._comm.wait_stream(torch.cuda.current_stream())
+        self.comm.all_gather(self.dcolor_local.view(-1), self.dcolor_all.view(-1), self._comm)
+        self._ev_gather.record(self._comm)
+        self._gathered = True
+
+    def reduce_geometry_chunk(self, gbuf, first, count, ready=None, group=None):
+        self._geom_reduced = True
+        if ready is not None:
+            self._comm.wait_event(ready)
+        else:
+            self._comm.wait_stream(torch.cuda.current_stream())
+        self.comm.group_start()
+        for k in ("pos", "scale", "rot", "opacity"):
+            self.comm.all_reduce_sum(gbuf.views[k][first:first + count], self._comm)
+        self.comm.group_end()
+
+    def exchange(self, gbuf, rast, pos, campos_all, sh_degree, group=None, shn_tiled=False):
+        cur = torch.cuda.current_stream()
+        if not self._gathered:
+            self.gather_all(None)
+        if not self._geom_reduced:
+            self._ev_bwd.record(cur)
+            self._comm.wait_event(self._ev_bwd)
+            self.comm.all_reduce_sum(gbuf.flat_geom, self._comm)
+        self._ev_comm.record(self._comm)
+        cur.wait_event(self._ev_gather)                 # the SH rows need only the colour all-gather: rebuilt under the geometry all-reduce
+        rast.sh_grad_combine(pos, campos_all, self.dcolor_all, gbuf.views["sh0"], gbuf.views["shN"], sh_degree, shn_tiled=shn_tiled)
+        cur.wait_event(self._ev_comm)
+        self._gathered = False
+        self._geom_reduced = False

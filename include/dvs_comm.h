@@ -10,8 +10,10 @@
  * librccl is opened with dlopen() when the first communicator is created, so libdvsraster.so has no load-time dependency on it.
  * Bootstrap: rank 0 creates the RCCL unique id and serves it over TCP on the rendezvous address every launcher exports as MASTER_ADDR,
  * on a DEDICATED port (the launcher's own store already listens on MASTER_PORT): DVS_COMM_PORT if set, else MASTER_PORT + 1789. A
- * peer introduces itself with {magic, job nonce, rank}; rank 0 serves every rank at most once, ignores anything else, and every
- * step has a timeout (DVS_COMM_TIMEOUT_S, default 180 s: an error, never a hang). Plain C, int status codes as dvs_raster.h.
+ * peer introduces itself with {magic, job nonce, rank}, receives the id, acknowledges it and waits for rank 0's one-byte confirmation
+ * (three-way: a rank counts on rank 0 exactly when it returns "ok" itself — one that timed out on any step simply asks again and is
+ * answered again; it counts once); rank 0 ignores anything else, and every step has a timeout (DVS_COMM_TIMEOUT_S, default 180 s: an
+ * error, never a hang). Plain C, int status codes as dvs_raster.h.
  *
  * DVS_COMM_BACKEND=tcp selects a TEST-ONLY backend: the same calls, executed host-staged over the bootstrap sockets (star on rank 0,
  * sums formed in rank order, every call synchronous). It needs neither librccl nor distinct devices per rank, which is the point: two
@@ -42,6 +44,10 @@ int dvs_comm_bootstrap(int rank, int world, const char* master_addr, int master_
 void      dvs_comm_destroy(dvs_comm* comm);
 int       dvs_comm_rank(const dvs_comm* comm);
 int       dvs_comm_world(const dvs_comm* comm);
+/* What the BACKEND says: the size the RCCL communicator reports (ncclCommCount; -1 if this librccl has no such call), or — test backend —
+ * the ranks rank 0 holds a socket to (+ itself). bench.py prints it as `rccl_nranks`: "RCCL saw N ranks" readable without the source. */
+int       dvs_comm_backend_ranks(const dvs_comm* comm);
+const char* dvs_comm_backend_name(const dvs_comm* comm);      /* "rccl" | "tcp (host-staged TEST backend)" */
 
 /* Collectives on DEVICE buffers, enqueued on `stream` (hipStream_t as void*), asynchronous. Counts are in elements. */
 int dvs_comm_all_reduce_sum_f32(dvs_comm* comm, void* stream, float* buf, size_t count);                 /* in place */

@@ -11,11 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(exchange, port, vps=1):
-    env = dict(os.environ, DVS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+def _run(exchange, port, vps=1, impl="torch", extra=()):
+    """two ranks of bench.py on the one GPU of the test box: impl "torch" over gloo, impl "dvs_comm" over the test-only TCP backend of
+    include/dvs_comm.h (RCCL needs one device per rank)"""
+    env = dict(os.environ, DVS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", DVS_COMM_BACKEND="tcp")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--workload", "C2", "--no-cpu-baseline", "--profile-iters", "0", "--exchange", exchange, "--views-per-step", str(vps)]
+           "--workload", "C2", "--no-cpu-baseline", "--profile-iters", "0", "--exchange", exchange, "--views-per-step", str(vps),
+           "--exchange-impl", impl] + list(extra)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -24,9 +27,10 @@ def _run(exchange, port, vps=1):
 
 def test_bench_self_launch_two_ranks(gpu_device):
     """`python bench.py --gpus 2 --steps 3` exactly as the driver types it (no launcher around it): bench.py starts its two ranks itself
-    under torch.distributed.run; here they share the one GPU of the test box over gloo. Rank 0 prints the one JSON line of BASELINE
-    config C4 (8 views per iteration, 4 per rank, strong scaling)."""
-    env = dict(os.environ, DVS_DIST_BACKEND="gloo")
+    under torch.distributed.run and exchanges through the product's layer (include/dvs_comm.h); here the two ranks share the one GPU of
+    the test box, so the communicator is the test-only TCP backend (on a node with two GPUs the same command runs RCCL). Rank 0 prints the
+    one JSON line of BASELINE config C4 (8 views per iteration, 4 per rank, strong scaling), which says who ran the collectives."""
+    env = dict(os.environ, DVS_COMM_BACKEND="tcp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True,
@@ -38,6 +42,12 @@ def test_bench_self_launch_two_ranks(gpu_device):
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "strong"
     assert rec["config"]["views_per_step"] == 8 and rec["config"]["views_per_gpu_per_step"] == 4
     assert rec["value"] > 0 and rec["t_comm_exposed_ms_per_step"] is not None
+    assert rec["rccl_nranks"] == 2 and "tcp" in rec["exchange"]["backend"] and rec["exchange"]["impl"].startswith("dvs_comm")
+    assert len(rec["per_rank_compute_ms"]) == 2 and min(rec["per_rank_compute_ms"]) > 0
+    m = rec["scaling_model"]
+    assert m["predicted_views_per_s"] > 0 and abs(m["measured_ms_per_step"] - rec["ms_per_step"]) < 1e-9
+    for k in ("all_reduce_geometry_44B_per_splat", "all_gather_dcolor_12B_per_splat_and_view"):
+        assert rec["comm_microbench"][k]["busbw_GBps"] > 0
 
 
 @pytest.mark.parametrize("vps", [1, 2])
@@ -50,6 +60,23 @@ def test_factorised_exchange_equals_allreduce(gpu_device, vps):
     for k, v in a["grad_l2_after_exchange"].items():
         assert v > 0
         assert abs(f["grad_l2_after_exchange"][k] - v) <= 1e-4 * v, (k, v, f["grad_l2_after_exchange"][k])
+
+
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_dvs_comm_exchange_two_ranks_equals_torch_path(gpu_device, chunks):
+    """bench.py's N>1 step routed through the product's communication layer (include/dvs_comm.h: early colour
+    all-gather, A9 in `chunks` splat chunks with one grouped launch each, SH rebuild under the geometry all-reduce) with two ranks over
+    the test-only TCP backend leaves the same gradients as the torch.distributed path (gloo) — and as the plain all-reduce of all rows
+    through the same layer."""
+    t = _run("factorised", 29561 + 8 * chunks, 1, impl="torch")
+    d = _run("factorised", 29563 + 8 * chunks, 1, impl="dvs_comm", extra=("--a9-chunks", str(chunks)))
+    a = _run("allreduce", 29565 + 8 * chunks, 1, impl="dvs_comm")
+    assert d["rccl_nranks"] == 2 and d["exchange"]["a9_chunks"] == (chunks if chunks > 1 else 1) and d["config"]["early_gather"]
+    assert t["exchange"]["impl"].startswith("torch") and t["rccl_nranks"] == 2
+    for k, v in t["grad_l2_after_exchange"].items():
+        assert v > 0
+        assert abs(d["grad_l2_after_exchange"][k] - v) <= 1e-4 * v, ("dvs_comm factorised", k, v, d["grad_l2_after_exchange"][k])
+        assert abs(a["grad_l2_after_exchange"][k] - v) <= 1e-4 * v, ("dvs_comm allreduce", k, v, a["grad_l2_after_exchange"][k])
 
 
 def test_pipelined_views_accumulate_like_sequential(gpu_device):
@@ -68,10 +95,11 @@ def test_pipelined_views_accumulate_like_sequential(gpu_device):
 
 def test_bench_step_over_rccl_one_rank(gpu_device):
     """bench.py's N>1 step — colour gradients taken from the A8 rows, their all-gather on the side stream under A9, geometry
-    all-reduce, SH rows rebuilt — executed over backend "nccl" (RCCL) with a 1-rank communicator, both exchanges: the gradient norms
+    all-reduce, SH rows rebuilt — executed by RCCL with a 1-rank communicator, both exchanges, through BOTH layers: the product's
+    include/dvs_comm.h (default; the line must say that RCCL saw one rank) and torch.distributed's backend "nccl": the gradient norms
     must equal the plain single-process step."""
     import socket
-    def run(force, exchange):
+    def run(force, exchange, impl="dvs_comm"):
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if force:
@@ -79,15 +107,19 @@ def test_bench_step_over_rccl_one_rank(gpu_device):
         else:
             env.pop("DVS_FORCE_COLLECTIVES", None)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "C2", "--no-cpu-baseline",
-               "--profile-iters", "0", "--global-views", "2", "--exchange", exchange]
+               "--profile-iters", "0", "--global-views", "2", "--exchange", exchange, "--exchange-impl", impl]
+        env.pop("DVS_COMM_BACKEND", None)                                  # RCCL itself
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     plain = run(False, "factorised")
     assert plain["comm_microbench"] is None and not plain["config"]["early_gather"]
-    for exchange in ("factorised", "allreduce"):
-        forced = run(True, exchange)
+    for exchange, impl in (("factorised", "dvs_comm"), ("allreduce", "dvs_comm"), ("factorised", "torch"), ("allreduce", "torch")):
+        forced = run(True, exchange, impl)
         assert forced["comm_microbench"] is not None                      # the collectives ran (RCCL, world 1)
+        assert forced["rccl_nranks"] == 1 and forced["exchange"]["impl"].startswith(impl)
+        if impl == "dvs_comm":
+            assert forced["exchange"]["backend"] == "rccl"
         assert forced["config"]["early_gather"] == (exchange == "factorised")
         for k, v in plain["grad_l2_after_exchange"].items():
             assert abs(forced["grad_l2_after_exchange"][k] - v) <= 1e-4 * v, (exchange, k, v, forced["grad_l2_after_exchange"][k])

@@ -18,7 +18,7 @@ import numpy as np
 
 KEYS = ("pos", "sh0", "shN", "opacity", "scale", "rot")
 # gaussian_trainer_scene.hpp (defaults of GaussianTrainConfig; names gs_train.cpp:52-57)
-LR = dict(poslrInit=0.00016, poslrFinal=0.0000016, featurelr=0.0025, opacitylr=0.05, scalinglr=0.005, rotationlr=0.001)
+LR = dict(poslrInit=0.00016, poslrFinal=0.0000016, featurelr=0.0025, opacitylr=0.05, scalinglr=0.001, rotationlr=0.001)
 
 
 def camera_stream(n_cams, count, single_camera=False):
