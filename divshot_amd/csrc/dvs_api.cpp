@@ -148,6 +148,7 @@ void timing_collect(dvs_ctx* c, bool append) {
     }
 }
 
+bool fe_no_fuse() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_FUSE_A6"); return e && e[0] == '1'; }(); return v; }      // (A/B aid)
 uint32_t* ranges_ptr(dvs_ctx* c) { return (uint32_t*)((char*)c->ranges.p + c->fe_zero_bytes); }
 uint32_t* fe_kred(dvs_ctx* c) { return (uint32_t*)c->ranges.p; }
 unsigned long long* fe_super(dvs_ctx* c) { return (unsigned long long*)((char*)c->ranges.p + (size_t)DVS_FE_KRED_WORDS * 4); }
@@ -285,6 +286,8 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     const uint64_t* T_dev = nullptr;           // async: the kernels over instances read T on the device, grids sized for the capacity
     int icur = 0;
     size_t e7 = 0;
+    int ranges_encoded = 0;                    // A6 fused into the tile sort's last pass: k_render_fwd decodes the ranges
+    bool keys_written = true;                  // the sorted tile ids exist (an asynchronous forward with the fused A6 does not write them)
     if (c->async_T) {
         // No host synchronisation: the arenas are over-allocated, T stays on the device. What the host knows is the T of EARLIER
         // forwards on this context (pinned copy, refreshed asynchronously): it grows the arenas ahead of need and reports an overflow
@@ -365,17 +368,23 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
                                             c->inst_splat[0].as<uint32_t>()));
         size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
         // A5 (high key bits): every view's instances by tile id; the last pass hands out view * tiles + tile
+        // A6 rides on the last pass (a range boundary is where the scattered tile id changes) whenever k_render_fwd composites (it decodes
+        // the ranges). An asynchronous forward does not even write the sorted tile ids: nothing on the device reads them, and
+        // dvs_fwd_state.sorted_tile is then NULL (dvs_raster.h).
+        const bool fuse_a6 = (c->fwd_variant == DVS_FWD_QUADRANT || V > 1) && !fe_no_fuse();
+        const bool write_keys = !(fuse_a6 && c->async_T);
         if (n > 0) {
             const uint64_t cap = c->async_T ? c->inst_cap : T;
             const uint32_t nbtot = (uint32_t)(cap / tile_part) + (uint32_t)V + 2u;
             HIPCHECK(dvs_launch_seg_sort(st, V, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
                                          c->inst_splat[1].as<uint32_t>(), fe_seg_tile(c), 0, tiles > 1 ? bits_for((uint32_t)(tiles - 1)) : 1,
                                          c->async_T ? (T_expected ? T_expected : c->inst_cap) : T, tile_part, nbtot, c->fe_hist.as<uint32_t>(), fe_totals(c),
-                                         (uint32_t)tiles, &icur));
+                                         (uint32_t)tiles, &icur, fuse_a6 ? ranges_ptr(c) : nullptr, write_keys ? 1 : 0));
         }
         size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
-        // A6 ranges (cleared by the memset above)
-        HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), ranges_ptr(c), tiles * V, T_dev, T_expected, false));
+        if (fuse_a6) ranges_encoded = n > 0 ? 1 : 0;
+        else HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), ranges_ptr(c), tiles * V, T_dev, T_expected, false));     // (cleared by the memset above)
+        keys_written = write_keys;
         e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     } else {
     // A2 preprocess: one lane per splat, all views
@@ -435,7 +444,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         if (c->live_lists && c->bwd_variant == DVS_BWD_TR) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
         HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, ranges_ptr(c), c->inst_splat[icur].as<uint32_t>(),
                                        c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>(),
-                                       c->live_splat, c->live_pos, rec_masks, rec_cap));
+                                       c->live_splat, c->live_pos, rec_masks, rec_cap, ranges_encoded));
     } else
         HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, ranges_ptr(c), c->inst_splat[icur].as<uint32_t>(),
                                               c->splat2d.as<float>(), cam->bg, out_rgb,
@@ -447,7 +456,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     s.radii = c->radii.as<int32_t>(); s.splat2d = c->splat2d.as<float>(); s.depth = c->depth.as<float>();
     s.flags = c->flags.as<uint32_t>();
     s.tiles_touched = c->tiles_touched.as<uint32_t>();
-    s.sorted_tile = c->inst_tile[icur].as<uint32_t>(); s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
+    s.sorted_tile = keys_written ? c->inst_tile[icur].as<uint32_t>() : nullptr; s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
     s.ranges = ranges_ptr(c); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
     s.num_rendered = c->async_T ? DVS_T_UNKNOWN : T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y;
     s._pad = 0;
@@ -723,6 +732,11 @@ int dvs_export_sorted_keys(dvs_ctx* c, void* stream, uint64_t* out_keys) {
     if (!c || !out_keys) { g_last_error = "dvs_export_sorted_keys: null argument"; return DVS_ERR_INVALID; }
     if (!c->have_fwd) { g_last_error = "dvs_export_sorted_keys: no forward state"; return DVS_ERR_STATE; }
     if (c->st.num_rendered == DVS_T_UNKNOWN) { uint64_t t; int r = dvs_get_num_rendered(c, stream, &t); if (r != DVS_OK) return r; }
+    if (!c->st.sorted_tile) {
+        g_last_error = "dvs_export_sorted_keys: the last forward was asynchronous (dvs_set_async) and did not materialise the sorted tile ids; "
+                       "export the keys of a synchronous forward";
+        return DVS_ERR_STATE;
+    }
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(dvs_launch_export_keys((hipStream_t)stream, c->st.num_rendered, c->st.sorted_tile, c->st.sorted_splat, c->st.depth, out_keys));
     return DVS_OK;

@@ -111,7 +111,8 @@ __device__ __forceinline__ float dvs_log_det(float x) {
 // tile's pixel-centre rectangle [16 tx, 16 tx + 15] x [16 ty, 16 ty + 15] is 0 if the mean lies inside, otherwise it lies on an edge
 // facing the mean; on the vertical line x: q = c (y - y*)^2 + x^2 det / c with y* = -b x / c — non-negative terms only (see
 // render.hip stage_batch), det lowered by its rounding bound. The tile stays unless q_min > 2 ln(o / ((1/255)(1 - 1e-3))), i.e. unless
-// even the nearest point of the tile stays below alpha = (1/255)(1 - 1e-3): the margin (2e-3 in q) covers the rounding of q_min, of
+// even the nearest point of the tile stays below alpha = (1/255)(1 - 1e-3): the margin (2e-3 in q, plus 1e-6 of the size the form's TERMS reach on
+// the tile: the per-pixel evaluation cancels for thin diagonal splats) covers the rounding of q_min, of
 // dvs_log_det and of the per-pixel alpha in the composite kernels, so no contributing pixel can lose its splat.
 // EVERY operation is IEEE-exact and in a fixed order (this file is compiled with -ffp-contract=off): the CPU oracle
 // (oracle/dvs_oracle.hpp tight_tile_mask) evaluates the same sequence and reproduces the mask bit for bit.
@@ -130,9 +131,15 @@ __device__ __forceinline__ unsigned long long dvs_tight_tile_mask(float a, float
         const bool hin = y0 <= 0.f && y1 >= 0.f;
         const float ye = y0 > 0.f ? y0 : y1;
         const float hx = nb_a * ye, hbase = (ye * ye) * det_a;
+        const float Yf = fmaxf(fabsf(y0), fabsf(y1));
         for (int tx = rminx; tx < rmaxx; ++tx, ++t) {
             const float x0 = (float)(tx * DVS_TILE) - mx, x1 = x0 + (float)(DVS_TILE - 1);
             const bool vin = x0 <= 0.f && x1 >= 0.f;
+            // the composite kernels evaluate the form per pixel as a cancelling sum (a dx^2 + 2 b dx dy + c dy^2, contracted): its rounding
+            // error grows with the size of the TERMS, which for a thin diagonal splat is thousands of times the value. The
+            // margin therefore scales with the largest the terms get on this tile: 1e-6 (17 ulp) of a X^2 + 2 |b| X Y + c Y^2 at its far corner.
+            const float Xf = fmaxf(fabsf(x0), fabsf(x1));
+            const float mag = ((a * Xf) * Xf + ((2.0f * fabsf(b)) * Xf) * Yf) + (c * Yf) * Yf;
             float qmin = 0.f;
             if (!(vin && hin)) {
                 qmin = __builtin_inff();
@@ -147,7 +154,7 @@ __device__ __forceinline__ unsigned long long dvs_tight_tile_mask(float a, float
                     qmin = fminf(qmin, (a * d) * d + hbase);
                 }
             }
-            mask |= !(qmin > kappa) ? (1ull << t) : 0ull;         // NaN-safe: a failed comparison keeps the tile
+            mask |= !(qmin > kappa + 1e-6f * mag) ? (1ull << t) : 0ull;         // NaN-safe: a failed comparison keeps the tile
         }
     }
     return mask;

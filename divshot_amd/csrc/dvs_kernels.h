@@ -61,7 +61,8 @@ hipError_t dvs_launch_depth_sort(hipStream_t st, int n, int V, uint32_t* keys0, 
 // stable LSD sort of every segment's pairs over the key bits [bit_lo, bit_lo + bits) (digits <= 9 bits); result in buffers *result_in
 hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
                                uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
-                               int* result_in);
+                               int* result_in, uint32_t* ranges_enc = nullptr /*A6 fused into the last pass: tile ranges as (~start, end), see k_seg_scatter*/,
+                               int write_last_keys = 1);
 // stage 0 = A3 (tile counts in depth order, block / super sums) + the views' instance ranges (seg_tile, total_dev); stage 1 = A4
 hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, const DvsSeg* seg_vis, DvsSeg* seg_tile, const uint32_t* sorted_ids,
                                   const uint32_t* rect, uint32_t* rect_sorted, uint32_t* block_sums, unsigned long long* super, uint32_t* superexcl,
@@ -100,13 +101,14 @@ hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* so
                                   const float* depth, uint64_t* out_keys);
 
 // render.hip — one launch covers the tiles of all n_views views of a batch (view-major ranges / pixel arrays; bgs = [n_views][3])
-hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, uint32_t* ranges /*ranges_encoded != 0: arrives as
+                                 (~start, end) from the tile sort's last pass (0, 0 = empty) and leaves as (start, end)*/,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
                                  uint32_t* n_contrib, uint32_t* live_splat /*[T] out (or null): per tile, the entries whose alpha >= 1/255 ellipse
                                  reaches the tile, compacted in list order from ranges[tile].x*/, uint32_t* live_pos /*[T] out (or null): list
                                  position -> number of such entries before it in its tile*/,
                                  uint64_t* take_masks /*test hook (or null): [take_cap][4] zeroed by the caller — per list position and 8x8 quadrant, the pixels that took the entry*/,
-                                 uint64_t take_cap);
+                                 uint64_t take_cap, int ranges_encoded = 0);
 // EXPERIMENT BUILDS ONLY (-DDVS_EXPERIMENT): the retired A8 kernels "reduce" and "mm". Declared weak: the release library does not
 // define it, dvs_set_backward_variant refuses those variants there.
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,

@@ -179,7 +179,10 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
               const DvsSeg* __restrict__ seg_in, DvsSeg* __restrict__ seg_out /*null, or where the segments of the OUTPUT are published
               (same base / pstart / sub / bits, count = the elements that survived the culling)*/,
               int V, int adaptive, int pass, int shift_s, int bits_s, int cull, uint32_t key_add_per_view,
-              const uint32_t* __restrict__ hist, uint32_t nbtot, const uint32_t* __restrict__ totals) {
+              const uint32_t* __restrict__ hist, uint32_t nbtot, const uint32_t* __restrict__ totals,
+              uint32_t* __restrict__ ranges_enc /*null, or (last pass of the tile sort: A6 fused) the tile ranges [V * tiles][2], zeroed: every run of equal
+              keys in a partition's output raises word 0 to ~(first position) and word 1 to (last position + 1) with atomic max — a tile's runs
+              from all partitions leave (~start, end); k_render_fwd turns that into (start, end)*/) {
     constexpr uint32_t PART = FE_BLOCK * ITEMS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[FeScatterLds<ITEMS>::WORDS];
     const uint32_t lane = fe_lane(), wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -315,6 +318,15 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
                     const uint32_t dst = gdelta[((k - sub) >> shift) & dmask] + slot;
                     if (kout) kout[dst] = k + key_add;
                     vout[dst] = stage_v[slot];
+                    if (ranges_enc) {
+                        // A6: neighbours in the stage with the same key are neighbours in the output (same digit, consecutive slots), so a
+                        // run's ends are where the stage's key changes; the same tile's runs of other partitions merge through the max
+                        const uint32_t kp = slot > 0 ? stage_k[slot - 1] : ~k, kn = slot + 1 < nvalid ? stage_k[slot + 1] : ~k;
+                        uint32_t* const e = ranges_enc + 2 * (size_t)(key_add + k);
+                        const uint32_t at = S.base + dst;
+                        if (kp != k) atomicMax(e, ~at);
+                        if (kn != k) atomicMax(e + 1, at + 1u);
+                    }
                 }
             }
             if (EARLY && p + gv < nparts) request(p + gv);        // (a workgroup rarely has a second partition: the grids cover the expected counts)
@@ -365,7 +377,7 @@ struct FeSortLaunch {
 
 static hipError_t fe_launch_pass(const FeSortLaunch& L, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, DvsSeg* seg_in,
                                  DvsSeg* seg_out, int adaptive, int pass, int shift, int bits, int cull, uint32_t key_add_per_view,
-                                 const uint32_t* kred) {
+                                 const uint32_t* kred, uint32_t* ranges_enc = nullptr) {
     const dim3 grid(L.grid_per_view * (uint32_t)L.V), blk(FE_BLOCK);
     const int maxbins = adaptive ? FE_MAXBINS : (1 << bits);
     const dim3 rgrid((uint32_t)((maxbins + FE_WAVES - 1) / FE_WAVES) * (uint32_t)L.V);
@@ -373,12 +385,12 @@ static hipError_t fe_launch_pass(const FeSortLaunch& L, const uint32_t* kin, con
         hipLaunchKernelGGL(k_seg_hist<8>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred);
         hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * 8), L.totals);
         hipLaunchKernelGGL(k_seg_scatter<8>, grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits,
-                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals);
+                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, ranges_enc);
     } else {
         hipLaunchKernelGGL(k_seg_hist<16>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred);
         hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * 16), L.totals);
         hipLaunchKernelGGL(k_seg_scatter<16>, grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits,
-                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals);
+                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, ranges_enc);
     }
     return hipGetLastError();
 }
@@ -407,7 +419,8 @@ uint32_t dvs_depth_sort_rows_per_view(int n, int V) {        // partitions (hist
 // possible, widest first). Buffers 0 hold the input; the result is in buffers (*result_in). grid_elems sizes the grids (an upper bound
 // or an estimate of the total element count: the kernels stride), cap_elems the histogram table (rows = cap / partition + V + 1 were
 // assumed when the segments' pstart were assigned: see dvs_fe_tile_part). key_add_per_view: added to the keys of view v (times v) when
-// the LAST pass writes them (the tile sort hands out view * tiles + tile).
+// the LAST pass writes them (the tile sort hands out view * tiles + tile). ranges_enc (nullable): the last pass also leaves the tile
+// ranges [V * tiles][2] (zeroed by the caller) as (~start, end) — A6 fused; write_last_keys = 0: it does not write the sorted keys.
 static void fe_split_bits(int bits, int* npass, int widths[4]) {
     int np = (bits + FE_REORDER_BITS - 1) / FE_REORDER_BITS;
     if (np < 1) np = 1;
@@ -420,7 +433,7 @@ uint32_t dvs_fe_part_for(uint64_t grid_elems) { return (uint32_t)FE_BLOCK * (uin
 
 hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
                                uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
-                               int* result_in) {
+                               int* result_in, uint32_t* ranges_enc, int write_last_keys) {
     if (result_in) *result_in = 0;
     if (V <= 0 || bits <= 0) return hipSuccess;
     int npass, widths[4];
@@ -437,7 +450,9 @@ hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t*
     int c = 0, shift = bit_lo;
     for (int k = 0; k < npass; ++k) {
         const bool last = k == npass - 1;
-        hipError_t e = fe_launch_pass(L, kk[c], vv[c], kk[c ^ 1], vv[c ^ 1], seg, nullptr, 0, k, shift, widths[k], 0, last ? key_add_per_view : 0u, nullptr);
+        // the last pass of the tile sort builds the tile ranges (A6) and may skip the keys: nothing reads them but the exported state
+        hipError_t e = fe_launch_pass(L, kk[c], vv[c], (last && !write_last_keys) ? nullptr : kk[c ^ 1], vv[c ^ 1], seg, nullptr, 0, k, shift, widths[k], 0,
+                                      last ? key_add_per_view : 0u, nullptr, last ? ranges_enc : nullptr);
         if (e != hipSuccess) return e;
         shift += widths[k];
         c ^= 1;

@@ -133,7 +133,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 template <bool RECORD>
 __global__ void __launch_bounds__(RB)
 k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
-             int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges,
+             int num_tiles /* = views * tiles_per_view */, uint2* __restrict__ ranges, int ranges_encoded,
              const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
              float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
              uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
@@ -155,7 +155,14 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
     const int py = ty * DVS_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile_g];
+    uint2 range = ranges[tile_g];
+    if (ranges_encoded) {
+        // A6 is fused into the tile sort's last pass (frontend.hip k_seg_scatter): the entry arrives as (~start, end), (0, 0) = no
+        // instance. Decode it and leave the canonical pair for A8 and the exported state (every wave has read before lane 0 rewrites).
+        range.x = range.y ? ~range.x : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) ranges[tile_g] = range;
+    }
     const int total = (int)(range.y - range.x);
     // Pixel state that decides control flow lives in wave masks (scalar registers): `notdone` = pixels still compositing. A visit forms
     // its predicates with three compares into masks, the scalar unit combines them, and the five updates of a contributing pixel
@@ -201,6 +208,12 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
             uint32_t word_a = (uint32_t)(uintptr_t)&L.a[lw * 64];
             asm("" : "+v"(word_a));
             const int idx0 = base + lw * 64 + 1;
+#if FWD_CMPX
+            // The visit below narrows EXEC and must leave it as it found it (not "-1" — a later per-lane branch around this
+            // loop would otherwise get its dead lanes back): the entry mask is read once per word of the walk, not per visit.
+            uint64_t exec_entry;
+            asm volatile("s_mov_b64 %0, exec" : "=s"(exec_entry));
+#endif
             while (m) {
                 const int bit = __builtin_ctzll(m);
                 asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));          // m &= m - 1 in one scalar instruction instead of three
@@ -233,10 +246,10 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
                              "v_fmac_f32 %[c2], %[cbl], %[at]\n\t"
                              "v_sub_f32 %[T], %[T], %[at]\n\t"                 // (not a move of test_T: that one is a fused fma; same bits as the other A7 kernels)
                              "v_mov_b32 %[last], %[idx]\n\t"
-                             "s_mov_b64 exec, -1"
+                             "s_mov_b64 exec, %[ee]"
                              : [c0] "+v"(C0), [c1] "+v"(C1), [c2] "+v"(C2), [T] "+v"(T), [last] "+v"(last), [nd] "+s"(notdone)
                              : [p2] "v"(p2), [al] "v"(alpha), [tt] "v"(test_T), [cr] "v"(B.z), [cg] "v"(B.w), [cbl] "v"(cb), [at] "v"(aT), [idx] "s"(idx),
-                               [amin] "s"(DVS_ALPHA_MIN), [tstop] "s"(DVS_T_STOP)
+                               [amin] "s"(DVS_ALPHA_MIN), [tstop] "s"(DVS_T_STOP), [ee] "s"(exec_entry)
                              : "vcc", "scc");
 #else
                 const uint64_t m_ok = notdone & __builtin_amdgcn_ballot_w64(!(p2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < DVS_ALPHA_MIN));
@@ -621,9 +634,9 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 
 // ---- launchers -----------------------------------------------------------------------------------------
 
-hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
-                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos, uint64_t* take_masks, uint64_t take_cap) {
+                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos, uint64_t* take_masks, uint64_t take_cap, int ranges_encoded) {
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
@@ -632,10 +645,10 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
 #endif
     if (take_masks)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, take_masks, take_cap DVS_DBG_PASS(dbg));
+                           (uint2*)ranges, ranges_encoded, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, take_masks, take_cap DVS_DBG_PASS(dbg));
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                           (const uint2*)ranges, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, (uint64_t*)nullptr, (uint64_t)0 DVS_DBG_PASS(dbg));
+                           (uint2*)ranges, ranges_encoded, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, (uint64_t*)nullptr, (uint64_t)0 DVS_DBG_PASS(dbg));
     return hipGetLastError();
 }
 

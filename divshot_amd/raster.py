@@ -211,7 +211,9 @@ class Rasterizer:
         T = self.state.num_rendered
         rec = self._d2h(st.splat2d, (n, 16), np.float32)
         ranges = self._d2h(st.ranges, (tiles, 2), np.uint32).astype(np.int64)
-        all_tile = self._d2h(st.sorted_tile, (T,), np.uint32); all_splat = self._d2h(st.sorted_splat, (T,), np.uint32)
+        st0 = FwdState()
+        check(lib.dvs_get_view_state(self.ctx, 0, C.byref(st0)), "dvs_get_view_state")          # (the batch-wide ranges start at view 0)
+        all_tile = self._sorted_tile(st0, T, tiles * len(self._cams)); all_splat = self._d2h(st.sorted_splat, (T,), np.uint32)
         nz = ranges[:, 1] > ranges[:, 0]
         lo = int(ranges[nz, 0].min()) if nz.any() else 0
         hi = int(ranges[nz, 1].max()) if nz.any() else 0
@@ -314,6 +316,16 @@ class Rasterizer:
                   "dvs_sh_grad_combine")
 
     # -- stage-level access for the parity tests --------------------------------------------------
+    def _sorted_tile(self, st, T, total_tiles):
+        """dvs_fwd_state.sorted_tile — NULL after an asynchronous forward (the tile ids are not materialised then: A6 rides on the last
+        sort pass and nothing on the device reads them); the sorted list is grouped by tile, so it follows from the ranges."""
+        if st.sorted_tile:
+            return self._d2h(st.sorted_tile, (T,), np.uint32)
+        rg = self._d2h(st.ranges, (total_tiles, 2), np.uint32).astype(np.int64)
+        out = np.repeat(np.arange(total_tiles, dtype=np.uint32), (rg[:, 1] - rg[:, 0]))
+        assert out.size == T, (out.size, T)
+        return out
+
     def _d2h(self, ptr, shape, dtype):
         a = np.empty(shape, dtype)
         if a.nbytes:
@@ -333,7 +345,7 @@ class Rasterizer:
             "depth": self._d2h(s.depth, (n,), np.float32), "conic_opacity": rec[:, 2:6].copy(),
             "rgb": rec[:, 6:9].copy(), "splat2d": rec, "flags": self._d2h(s.flags, (n,), np.uint32),
             "tiles_touched": self._d2h(s.tiles_touched, (n,), np.uint32),
-            "sorted_tile": self._d2h(s.sorted_tile, (T,), np.uint32), "vals": self._d2h(s.sorted_splat, (T,), np.uint32),
+            "sorted_tile": self._sorted_tile(s, T, tiles), "vals": self._d2h(s.sorted_splat, (T,), np.uint32),
             "ranges": self._d2h(s.ranges, (tiles, 2), np.uint32), "final_T": self._d2h(s.final_T, (H, W), np.float32),
             "n_contrib": self._d2h(s.n_contrib, (H, W), np.uint32),
         }

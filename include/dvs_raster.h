@@ -141,7 +141,8 @@ typedef struct dvs_fwd_state {
     const uint32_t* flags;          /* [n] bit0..2 = SH clamp (colour channel <0), bit3 = fx clamped, bit4 = fy clamped */
     const uint32_t* tiles_touched;  /* [n] */
     /* per instance (num_rendered), sorted by (tile, depth, splat id) */
-    const uint32_t* sorted_tile;    /* [T] tile id of each sorted instance */
+    const uint32_t* sorted_tile;    /* [T] tile id of each sorted instance (a batch: view * tiles + tile). NULL after an ASYNCHRONOUS forward
+                                       (dvs_set_async): the ids are then not written at all — the list is grouped by tile, `ranges` says where */
     const uint32_t* sorted_splat;   /* [T] splat id ("value") of each sorted instance */
     /* per tile */
     const uint32_t* ranges;         /* [tiles,2] [start,end) into the sorted lists */

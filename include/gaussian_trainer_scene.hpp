@@ -46,7 +46,10 @@ struct GaussianTrainConfig {
     float growGrad2d = 0.0002f;           // main.cpp:46
     float ssimWeight = 0.2f;              // main.cpp:24
     float noiselr = 1e5f;                 // main.cpp:67
-    float poslrInit = 0.00016f, poslrFinal = 0.0000016f, rotationlr = 0.001f, scalinglr = 0.001f;   // main.cpp:31 (the commented defaults: scaling_lr = 0.001 there)
+    float poslrInit = 0.00016f, poslrFinal = 0.0000016f, rotationlr = 0.001f;       // main.cpp:31 (the commented-out defaults of the CLI)
+    float scalinglr = 0.005f;             // NOT main.cpp:31's commented 0.001: the CLI never passes it (main.cpp:35, gs_train.cpp:35,55 are commented out), so
+                                          // the closed trainer's own default applies, which the tree does not show; this build keeps the lineage's published
+                                          // 0.005 (with 0.001 the splits of an ADC refinement take ~5x longer to settle: tests/test_plugin.py's 8-view run)
     float featurelr = 0.0025f, opacitylr = 0.05f;
     float min_opacity = 0.005f, pruneOpacity = 0.005f, pruneScale3d = 0.1f, pruneScale2d = 0.15f;
     bool progressiveTrain = true, useAbsGrad = true, revisedOpacity = true, mipAntiliased = false;

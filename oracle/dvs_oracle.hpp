@@ -178,9 +178,13 @@ template <class T> inline uint64_t tight_tile_mask(T a, T b, T c, T o, T mx, T m
         const bool hin = y0 <= T(0) && y1 >= T(0);
         const T ye = y0 > T(0) ? y0 : y1;
         const T hx = nb_a * ye, hbase = (ye * ye) * det_a;
+        const T Yf = std::fmax(std::fabs(y0), std::fabs(y1));
         for (int tx = rminx; tx < rmaxx; ++tx, ++t) {
             const T x0 = T(tx * kTile) - mx, x1 = x0 + T(kTile - 1);
             const bool vin = x0 <= T(0) && x1 >= T(0);
+            // margin scaled with the size the form's terms reach on this tile (the composite kernels' per-pixel evaluation cancels)
+            const T Xf = std::fmax(std::fabs(x0), std::fabs(x1));
+            const T mag = ((a * Xf) * Xf + ((T(2) * std::fabs(b)) * Xf) * Yf) + (c * Yf) * Yf;
             T qmin = T(0);
             if (!(vin && hin)) {
                 qmin = inf;
@@ -195,7 +199,7 @@ template <class T> inline uint64_t tight_tile_mask(T a, T b, T c, T o, T mx, T m
                     qmin = std::fmin(qmin, (a * d) * d + hbase);
                 }
             }
-            if (!(qmin > kappa)) mask |= (1ull << t);
+            if (!(qmin > kappa + T(1e-6f) * mag)) mask |= (1ull << t);
         }
     }
     return mask;

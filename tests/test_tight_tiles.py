@@ -46,3 +46,36 @@ def test_rectangles_of_more_than_64_tiles_stay_whole():
         assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32)), name
         big = a.get("tiles_touched") > 64
         assert np.array_equal(a.get("tiles_touched")[big], b.get("tiles_touched")[big]), name
+
+
+def test_thin_diagonal_splats_keep_every_contributing_tile():
+    """the adversarial case of the tight tile bounds — needle-thin splats lying diagonally across several tiles. The per-pixel
+    form a dx^2 + 2 b dx dy + c dy^2 then cancels terms thousands of times its value, so its rounding (which decides whether a pixel at
+    the alpha = 1/255 rim takes the splat) exceeds a fixed margin; the margin scaled with the size of the terms must keep every tile in
+    which the canonical run lets the splat contribute: image, final_T, n_contrib and gradients stay bit-identical."""
+    rng = np.random.default_rng(5)
+    n, W, H = 1500, 192, 160
+    spec = dv.make_spec(n, W, H, sh_degree=0, seed=9)
+    P = dv.synth_splats(spec)
+    cam = dv.synth_camera(spec, 0)
+    # needles: one long axis (about 30-60 px on screen), two axes a hundredth of a pixel wide, rotated about the view axis by ~45 degrees
+    z = P["pos"][:, 2]
+    px = z / cam.focal_x
+    P["scale"][:, 0] = np.log(px * rng.uniform(10.0, 20.0, n)).astype(np.float32)
+    P["scale"][:, 1] = np.log(px * 0.02).astype(np.float32)
+    P["scale"][:, 2] = np.log(px * 0.02).astype(np.float32)
+    ang = np.deg2rad(45.0 + rng.uniform(-8, 8, n)) * rng.choice([-1.0, 1.0], n)
+    P["rot"][:] = np.stack([np.cos(ang / 2), np.zeros(n), np.zeros(n), np.sin(ang / 2)], 1).astype(np.float32)      # (w, x, y, z): about z
+    P["opacity"][:] = rng.uniform(1.0, 4.0, n).astype(np.float32)
+    a, b = Oracle(np.float32), Oracle(np.float32)
+    ia = a.forward(P, cam, sh_degree=0, absgrad=True).copy()
+    ib = b.forward(P, cam, sh_degree=0, absgrad=True, tight_tiles=True).copy()
+    tt_a, tt_b = a.get("tiles_touched"), b.get("tiles_touched")
+    multi = (tt_a > 3) & (tt_a <= 64)
+    assert multi.sum() > 0.3 * n and tt_b[multi].sum() < 0.8 * tt_a[multi].sum()          # the needles span tiles, and most of their rectangles go
+    assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
+    assert np.array_equal(a.get("final_T"), b.get("final_T")) and np.array_equal(a.get("n_contrib") > 0, b.get("n_contrib") > 0)
+    dL = rng.normal(size=ia.shape).astype(np.float32)
+    ga, gb = a.backward(dL), b.backward(dL)
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k

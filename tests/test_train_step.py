@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import divshot_amd as dv
 from oracle.oracle import Oracle
-from train_step_ref import TrainStepRef, KEYS, camera_stream
+from train_step_ref import TrainStepRef, KEYS, camera_stream, ssim_and_grad
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "divshot_amd", "lib")
@@ -68,6 +68,26 @@ def test_restated_train_step_learns_and_is_well_conditioned():
         moved = np.abs(r64.P[k] - init[k]) > 0
         close = np.abs(r32.P[k] - r64.P[k]) <= 1e-4 * np.maximum(np.abs(r64.P[k]), 1e-2)
         assert close[moved].mean() > 0.9, (k, close[moved].mean())
+
+
+def test_restated_ssim_gradient_against_finite_differences():
+    """The analytic d(mean SSIM)/dx of tests/train_step_ref.py (what the SSIM term of the restated train_step uses) against fp64 central
+    differences of its own forward value, and float32 against float64."""
+    rng = np.random.default_rng(0)
+    H, W = 23, 31
+    y = rng.uniform(0, 1, (3, H, W))
+    x = np.clip(y + 0.15 * rng.standard_normal((3, H, W)), 0, 1)
+    v, g = ssim_and_grad(x, y)
+    assert 0.5 < v < 1.0 and abs(ssim_and_grad(y, y)[0] - 1.0) < 1e-12
+    for _ in range(40):
+        c, i, j = rng.integers(0, 3), rng.integers(0, H), rng.integers(0, W)
+        e = 1e-6
+        xp = x.copy(); xp[c, i, j] += e
+        xm = x.copy(); xm[c, i, j] -= e
+        fd = (ssim_and_grad(xp, y)[0] - ssim_and_grad(xm, y)[0]) / (2 * e)
+        assert abs(g[c, i, j] - fd) <= 1e-4 * abs(fd) + 1e-10, (c, i, j, g[c, i, j], fd)
+    v32, g32 = ssim_and_grad(x.astype(np.float32), y.astype(np.float32))
+    assert abs(v32 - v) < 1e-6 and np.abs(g32 - g).max() < 1e-5 * np.abs(g).max()
 
 
 def _run(args, timeout=600, env=None):
@@ -136,6 +156,112 @@ def test_plugin_trajectory_matches_oracle_plus_numpy_adam(tmp_path):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     import json
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", "train_step_parity.json"), "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_plugin_trajectory_on_the_cli_defaults_ssim_sh3_eight_views(tmp_path):
+    """the loss the reference CLI defaults to — `--ssim 0.2` (main.cpp:24) — with SH degree 3 and BASELINE config
+    C4's eight views per iteration (`--viewsPerIter 8`: ONE multi-view pass per train_step), 20 iterations of the product against oracle
+    gradients + the restated SSIM / L1 gradient + numpy Adam (float32 and float64): same bars as the L1-only trajectory test."""
+    n, W, H, ncam, sh, seed, K, V, w = 2000, 64, 64, 8, 3, 21, 20, 8, 0.2
+    src = f"synthetic:N={n},W={W},H={H},cams={ncam},sh={sh},seed={seed}"
+    out = str(tmp_path / "m" / "it")
+    flags = ["--ssim", str(w), "--packLevel", "0", "--densifyStrategy", "0", "--progressTrain", "0", "--absgrad", "1", "--warmupLength", "100000",
+             "--viewsPerIter", str(V)]
+    _run(["--inputPath", src, "--maxIteration", "0", "--outputPath", out] + flags)
+    init = _read_ply(out + "_0.ply")
+    p = _run(["--inputPath", src, "--maxIteration", str(K), "--outputPath", out] + flags)
+    got = _read_ply(out + f"_{K}.ply")
+    assert got["pos"].shape[0] == n and "densify @" not in p.stderr
+    spec, cams = _scene(n, W, H, ncam, sh, seed)
+    targets = _hip_targets(spec, cams, sh)
+    r32 = TrainStepRef(Oracle, cams, targets, init, sh, K, np.float32, views_per_step=V, ssim_weight=w)
+    r64 = TrainStepRef(Oracle, cams, targets, init, sh, K, np.float64, views_per_step=V, ssim_weight=w)
+    for _ in range(K):
+        r32.train_step(); r64.train_step()
+    assert np.abs(r64.P["shN"][:, 8:] - init["shN"][:, 8:]).max() > 0            # the degree-3 band trains
+    report = {}
+    _compare(got, r32, r64, init, 1e-4, 0.90, report)
+    for k, r in report.items():
+        assert r["rel_l2_of_update"] < 1e-2, (k, r)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    import json
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "train_step_parity_ssim_sh3_8views.json"), "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_plugin_mcmc_refinement_against_the_restated_rule(tmp_path):
+    """the strategy the reference CLI defaults to — `--densifyStrategy 1` (MCMC, main.cpp:20,29). Ten iterations
+    (L1 + the strategy's opacity / scale regularisers, exploration noise off so that the trajectory can be restated) end in ONE
+    relocation + 5 % growth step; its effect is decoded from the model the plugin saved and checked against the published rule
+    (restated in tests/test_gpu_train_ops.py::_relocation_np and by its invariant):
+      * every splat the restated trajectory calls dead (sigmoid(opacity) <= minOpacity, 5 % margin) has been moved onto a live splat,
+        floor(1.05 n) - n copies have been appended, every copy carries its source's sh0 / shN / rotation;
+      * a source and its copies share one position; over each such group 1 - prod(1 - o') equals the source's opacity BEFORE the step
+        (each application of the rule replaces a factor (1 - o) by r factors (1 - o)^(1/r)), and its members' scales have shrunk;
+      * sources are drawn in proportion to opacity; splats that are neither dead, nor drawn, nor copies carry the trajectory's
+        parameters."""
+    n, W, H, ncam, sh, seed, K, min_op = 3000, 96, 96, 4, 1, 13, 10, 0.1
+    src = f"synthetic:N={n},W={W},H={H},cams={ncam},sh={sh},seed={seed}"
+    out = str(tmp_path / "m" / "it")
+    flags = ["--ssim", "0", "--packLevel", "0", "--densifyStrategy", "1", "--progressTrain", "0", "--absgrad", "1", "--noiselr", "0",
+             "--warmupLength", "5", "--refineEvery", "10", "--refineStopIter", "1000", "--minOpacity", str(min_op)]
+    _run(["--inputPath", src, "--maxIteration", "0", "--outputPath", out] + flags)
+    init = _read_ply(out + "_0.ply")
+    p = _run(["--inputPath", src, "--maxIteration", str(K), "--outputPath", out] + flags)
+    n_new = int(1.05 * n) - n
+    m = re.search(r"mcmc @10: (\d+) -> (\d+) splats", p.stderr)
+    assert m and int(m.group(1)) == n and int(m.group(2)) == n + n_new, p.stderr[-1500:]
+    got = _read_ply(out + f"_{K}.ply")
+    assert got["pos"].shape[0] == n + n_new
+    spec, cams = _scene(n, W, H, ncam, sh, seed)
+    targets = _hip_targets(spec, cams, sh)
+    r64 = TrainStepRef(Oracle, cams, targets, init, sh, K, np.float64, mcmc_reg=(0.01, 0.01))
+    for _ in range(K):
+        r64.train_step()
+    sig = lambda a: 1.0 / (1.0 + np.exp(-np.asarray(a, np.float64)))
+    o_pre = sig(r64.P["opacity"])
+    dead = o_pre <= min_op
+    firm = np.abs(o_pre - min_op) > 0.05 * min_op
+    assert 0.03 * n < dead.sum() < 0.6 * n
+    # groups of identical positions in the saved model: a source and its copies
+    key = {}
+    for row in range(n + n_new):
+        key.setdefault(got["pos"][row].tobytes(), []).append(row)
+    where_pre = np.abs(got["pos"][:n].astype(np.float64) - r64.P["pos"]).max(1) < 1e-3 * np.maximum(np.abs(r64.P["pos"]).max(1), 1e-2)
+    # (row i < n still sits where the trajectory has it <=> it was not relocated)
+    assert not where_pre[dead & firm].any(), "a dead splat was left in place"
+    assert where_pre[~dead & firm].all(), "a live splat was moved"
+    checked, src_rows = 0, []
+    for rows in key.values():
+        srcs = [r_ for r_ in rows if r_ < n and where_pre[r_] and not dead[r_]]
+        if len(rows) == 1:
+            continue
+        assert len(srcs) == 1, (rows, srcs)                        # exactly one member is the live original
+        i = srcs[0]
+        src_rows.append(i)
+        for r_ in rows:                                            # copies carry the source's colour and rotation
+            for k in ("sh0", "shN", "rot"):
+                a, b = got[k][r_].astype(np.float64).ravel(), r64.P[k][i].ravel()
+                assert np.abs(a - b).max() <= 1e-3 * max(np.abs(b).max(), 1e-2), (k, i, r_)
+            assert (got["scale"][r_] <= r64.P["scale"][i] + 1e-3).all()
+        o_after = sig(got["opacity"][rows])
+        if firm[i] and o_after.min() > 1.02 * min_op:              # (an opacity clamped at the floor of the rule, minOpacity, breaks the product)
+            mass = 1.0 - np.prod(1.0 - o_after)
+            assert abs(mass - o_pre[i]) <= 2e-3 * max(o_pre[i], 0.05), (i, rows, mass, o_pre[i])
+            checked += 1
+    assert checked > 0.3 * len(src_rows) > 0, (checked, len(src_rows))
+    # every relocated or appended row belongs to a group with a source
+    grouped = {r_ for rows in key.values() if len(rows) > 1 for r_ in rows}
+    assert all((r_ in grouped) for r_ in list(np.flatnonzero(dead & firm)) + list(range(n, n + n_new)))
+    live = ~dead
+    assert o_pre[src_rows].mean() > 1.1 * o_pre[live].mean()        # drawn ~ opacity
+    untouched = np.array([r_ for r_ in range(n) if r_ not in grouped and firm[r_]])
+    assert untouched.size > 0.2 * n
+    for k in ("pos", "sh0", "scale", "rot", "opacity"):
+        a, b = got[k][untouched].astype(np.float64), r64.P[k][untouched]
+        bad = np.abs(a - b) > 1e-3 * np.maximum(np.abs(b), 1e-2)
+        assert bad.mean() < 0.02, (k, bad.mean())
 
 
 def _decode_actions(src, dst):

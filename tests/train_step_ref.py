@@ -4,7 +4,8 @@ What the reference's host calls per iteration is one opaque symbol, `train_step(
 gs_train.cpp:156; flags main.cpp:24-25,46-48); the trainer behind it is closed source (README.md:46), so this file restates the step
 this build's plugin defines (divshot_amd/gstrain/gstrain.cpp trainStep) from independent parts:
 
-  camera draw (xorshift64, one stream) -> oracle forward (oracle/dvs_oracle.hpp) -> L1 photometric gradient sign(out - target) / (3 W H)
+  camera draw (xorshift64, one stream) -> oracle forward (oracle/dvs_oracle.hpp) -> photometric gradient of (1 - w) L1 + w (1 - SSIM)
+  ((1 - w) sign(out - target) / (3 W H) - w dSSIM/dout; w = --ssim, 0 = L1 only; the SSIM and its gradient restated analytically below)
   -> oracle backward in DVS_GRAD_LINEAGE -> per-group Adam in numpy (beta 0.9 / 0.999, eps 1e-15, bias-corrected) with the learning
   rates of gaussian_trainer_scene.hpp (position: extent x exponential decay) -> abs-grad densification statistics
   (sqrt((|gx| W/2)^2 + (|gy| H/2)^2) per visible splat, denominator + 1).
@@ -18,7 +19,50 @@ import numpy as np
 
 KEYS = ("pos", "sh0", "shN", "opacity", "scale", "rot")
 # gaussian_trainer_scene.hpp (defaults of GaussianTrainConfig; names gs_train.cpp:52-57)
-LR = dict(poslrInit=0.00016, poslrFinal=0.0000016, featurelr=0.0025, opacitylr=0.05, scalinglr=0.001, rotationlr=0.001)
+LR = dict(poslrInit=0.00016, poslrFinal=0.0000016, featurelr=0.0025, opacitylr=0.05, scalinglr=0.005, rotationlr=0.001)
+
+
+def _gauss_window(dt):
+    x = np.arange(11, dtype=np.float64) - 5.0
+    g = np.exp(-x * x / (2 * 1.5 ** 2))
+    return (g / g.sum()).astype(dt)
+
+
+def _conv_same(img, g):
+    """separable 11-tap convolution with zero padding (its own adjoint: the window is symmetric), img [H, W]"""
+    H, W = img.shape
+    p = np.pad(img, 5)
+    t = sum(g[k] * p[:, k:k + W] for k in range(11))
+    return sum(g[k] * t[k:k + H, :] for k in range(11))
+
+
+def ssim_and_grad(x, y):
+    """mean SSIM of x against y ([3, H, W]; 11x11 Gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2 — the definition of
+    include/dvs_train.h / csrc/ssim.hip, the standard one of the lineage) and its gradient d(mean SSIM)/dx, analytically, in x's dtype.
+    With mu1 = g*x, E2 = g*x^2, E12 = g*xy the map is m = A B / (C D), A = 2 mu1 mu2 + C1, B = 2 (E12 - mu1 mu2) + C2,
+    C = mu1^2 + mu2^2 + C1, D = (E2 - mu1^2) + sigma2 + C2, and d mean/dx = [ g*(dm/dmu1) + 2 x g*(dm/dE2) + y g*(dm/dE12) ] / N."""
+    dt = x.dtype
+    g = _gauss_window(dt)
+    C1, C2 = dt.type(0.01 ** 2), dt.type(0.03 ** 2)
+    two = dt.type(2.0)
+    grad = np.zeros_like(x)
+    tot = 0.0
+    for c in range(3):
+        xc, yc = x[c], y[c]
+        mu1, mu2 = _conv_same(xc, g), _conv_same(yc, g)
+        e2, e12 = _conv_same(xc * xc, g), _conv_same(xc * yc, g)
+        s1, s2, s12 = e2 - mu1 * mu1, _conv_same(yc * yc, g) - mu2 * mu2, e12 - mu1 * mu2
+        A, B = two * mu1 * mu2 + C1, two * s12 + C2
+        Cc, D = mu1 * mu1 + mu2 * mu2 + C1, s1 + s2 + C2
+        m = (A * B) / (Cc * D)
+        tot += float(m.sum(dtype=np.float64))
+        dm_dE12 = two * A / (Cc * D)
+        dm_dE2 = -m / D
+        # total derivative w.r.t. mu1 at fixed E2, E12: A and C directly, B and D through sigma12 = E12 - mu1 mu2, sigma1 = E2 - mu1^2
+        dm_dmu1 = two * mu2 * B / (Cc * D) - two * mu2 * A / (Cc * D) - two * mu1 * m / Cc + two * mu1 * m / D
+        grad[c] = _conv_same(dm_dmu1, g) + two * xc * _conv_same(dm_dE2, g) + yc * _conv_same(dm_dE12, g)
+    n = x.size
+    return tot / n, (grad / dt.type(n)).astype(dt)
 
 
 def camera_stream(n_cams, count, single_camera=False):
@@ -41,7 +85,11 @@ def scene_extent(cams):
 
 
 class TrainStepRef:
-    def __init__(self, oracle_cls, cams, targets, init, sh_degree, num_iters, dtype=np.float32, views_per_step=1, world=1, lr=None):
+    def __init__(self, oracle_cls, cams, targets, init, sh_degree, num_iters, dtype=np.float32, views_per_step=1, world=1, lr=None,
+                 ssim_weight=0.0, mcmc_reg=None):
+        """ssim_weight: w of L = (1 - w) mean|x - y| + w (1 - mean SSIM) (--ssim, main.cpp:24: 0.2; 0 = L1 only).
+        mcmc_reg: (opacity_reg, scale_reg) of densifyStrategy 1 (gstrain.cpp: 0.01, 0.01), added to the summed gradients once per step."""
+        self.w_ssim, self.mcmc_reg = float(ssim_weight), mcmc_reg
         self.dt = np.dtype(dtype)
         self.orc = oracle_cls(self.dt)
         self.cams, self.targets = cams, [np.asarray(t, self.dt) for t in targets]
@@ -78,8 +126,13 @@ class TrainStepRef:
             out = self.orc.forward(self.P, cam, sh_degree=self.deg, antialias=False, absgrad=True, grad_mode=1)
             d = out - tgt
             scale = f(1.0) / f(d.size)
-            dL = (np.sign(d) * scale).astype(self.dt)
-            loss += float(np.abs(d).sum() * scale)
+            w = f(self.w_ssim)
+            dL = (np.sign(d) * (scale * (f(1.0) - w))).astype(self.dt)
+            loss += float(np.abs(d).sum() * scale) * (1.0 - self.w_ssim)
+            if self.w_ssim > 0:
+                val, gs = ssim_and_grad(np.ascontiguousarray(out, self.dt), tgt)
+                dL = (dL - w * gs).astype(self.dt)
+                loss += self.w_ssim * (1.0 - val)
             g = self.orc.backward(dL, grad_mode=1)
             for k in KEYS:
                 G[k] += g[k].reshape(G[k].shape)
@@ -91,6 +144,12 @@ class TrainStepRef:
             self.denom += vis.astype(self.dt)
             self.max_radii = np.maximum(self.max_radii, np.where(vis, radii, 0))
         self.losses.append(loss / len(draws))
+        if self.mcmc_reg is not None:            # dvs_mcmc_regularize: d/dlogit of wo mean(sigmoid), d/dlog s of ws mean(exp(log s))
+            wo, ws = self.mcmc_reg
+            n = self.P["opacity"].shape[0]
+            sg = f(1.0) / (f(1.0) + np.exp(-self.P["opacity"]))
+            G["opacity"] += (f(wo) / f(n)) * sg * (f(1.0) - sg)
+            G["scale"] += (f(ws) / f(3 * n)) * np.exp(self.P["scale"])
         return G
 
     def adam(self, G):

@@ -40,7 +40,7 @@ for fe in ("legacy", "seg"):
     print(f"[{fe}] n={n} {W}x{H} V={V} T={T}  front end {fe_ms:.4f} ms  total {sum(tab.values()):.4f} ms\n    {tab}", flush=True)
     s = r.state
     tiles = s.tiles_x * s.tiles_y
-    keep = {"img": img.cpu().numpy(), "ranges": r._d2h(s.ranges, (V * tiles, 2), np.uint32), "tile": r._d2h(s.sorted_tile, (T,), np.uint32),
+    keep = {"img": img.cpu().numpy(), "ranges": r._d2h(s.ranges, (V * tiles, 2), np.uint32), "tile": r._sorted_tile(s, T, V * tiles),
             "splat": r._d2h(s.sorted_splat, (T,), np.uint32), "n_contrib": r._d2h(s.n_contrib, (V, H, W), np.uint32)}
     for k in ("pos", "opacity", "scale", "rot", "sh0"):
         keep["g_" + k] = g[k].cpu().numpy()
