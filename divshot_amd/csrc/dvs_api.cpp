@@ -70,15 +70,15 @@ struct dvs_ctx {
     int max_w = 0, max_h = 0;
     int max_views = 1;                   // views one forward can batch (dvs_create_views)
     int n_views = 1;                     // views of the last forward
-    Buf radii, splat2d, depth, flags, tiles_touched, rect, rect_sorted, key[2], ids[2], scan_blocks;
+    Buf radii, splat2d, depth, flags, tiles_touched, rect, rect_sorted, key[2], ids[2];
     Buf inst_tile[2], inst_splat[2];
     uint32_t* live_splat = nullptr;      // A7's compacted per-tile lists of the last forward (in the sort's spare instance arrays), or null
     uint32_t* live_pos = nullptr;
     bool live_lists = true;              // env DVS_LIVE_LISTS=0: A8 walks the full lists (A/B and parity of the two routes)
-    Buf sort_scratch, tmp_keys, tmp_vals;
+    Buf tmp_keys, tmp_vals;
+    Buf ranges_canon;                    // (start, end) per tile as k_render_fwd decodes them when A6 rides on the tile sort (frontend.hip)
     Buf ranges, final_T, n_contrib;      // `ranges` starts with the front end's zeroed words (fe_zero_bytes), the tile ranges follow: ONE memset per forward
-    // segmented front end (frontend.hip; the default). DVS_FRONTEND=legacy selects the batch-wide sort of rounds 1-4 (binning.hip) for A/B runs.
-    bool fe_seg = true;
+    // the binning front end (frontend.hip): every view is a segment of the sorts
     size_t fe_zero_bytes = 0;            // [kred: DVS_FE_KRED_WORDS u32][super sums: max_views x fe_nsb u64]
     uint32_t fe_nbv = 0, fe_nsb = 0;     // A3 workgroups / super sums per view at max_splats
     Buf fe_state;                        // [seg_all 16][seg_vis 16][seg_tile 16][superexcl V x nsb][totals V x 2048][block sums V x nbv]
@@ -90,10 +90,10 @@ struct dvs_ctx {
     uint64_t* total_dev = nullptr;       // [0] = T of the last forward, [1] = number of forwards whose T exceeded the instance capacity
     uint64_t* total_host = nullptr;      // pinned copy of both words (async: refreshed by every forward, read by the next one)
     uint64_t inst_cap = 0;               // instances the instance arenas can hold
+    uint64_t inst_grow_events = 0;       // how often they have been enlarged since dvs_create (dvs_get_arena_info)
     bool async_T = false;                // dvs_set_async: no host synchronisation inside dvs_raster_forward
     uint64_t* rec_masks = nullptr; uint64_t rec_cap = 0;      // dvs_debug_record_decisions
     uint64_t overflow_seen = 0;          // value of total_host[1] already reported
-    uint64_t lookback_seen = 0;          // value of total_host[2] already reported (DVS_SORT_ONESWEEP only)
     dvs_fwd_state st{};
     bool have_fwd = false;
     bool keep_rows = false;              // parity tests: leave the A8 rows in place after the backward
@@ -174,8 +174,6 @@ int ensure_splat_arenas(dvs_ctx* c, size_t n) {
 #define ENS(buf, bytes) if ((r = c->buf.ensure(bytes)) != DVS_OK) return r;
     ENS(radii, n * 4) ENS(splat2d, n * 64) ENS(depth, n * 4)
     ENS(flags, n * 4) ENS(tiles_touched, n * 4) ENS(rect, n * 16) ENS(rect_sorted, n * 16)     /* 8 B per (view, splat) canonically; 16 B with DVS_TILES_TIGHT (rectangle + tile mask) */ ENS(key[0], n * 4) ENS(key[1], n * 4) ENS(ids[0], n * 4) ENS(ids[1], n * 4)
-    ENS(scan_blocks, dvs_scan_scratch_words((int)n) * 4)
-    ENS(sort_scratch, dvs_sort_scratch_words(n) * 4)
     ENS(g_rows, n * 48)
 #undef ENS
     return DVS_OK;
@@ -185,24 +183,24 @@ int ensure_image_arenas(dvs_ctx* c, int w, int h, int views) {
     const size_t tiles = (size_t)((w + DVS_TILE - 1) / DVS_TILE) * ((h + DVS_TILE - 1) / DVS_TILE) * views;
     int r;
     if ((r = c->ranges.ensure(c->fe_zero_bytes + tiles * 8)) != DVS_OK) return r;
+    if ((r = c->ranges_canon.ensure(tiles * 8)) != DVS_OK) return r;
     if ((r = c->final_T.ensure(P * 4)) != DVS_OK) return r;
     if ((r = c->n_contrib.ensure(P * 4)) != DVS_OK) return r;
     return DVS_OK;
 }
 int ensure_instance_arenas(dvs_ctx* c, uint64_t T) {
     int r;
+    if (c->inst_cap && T > c->inst_cap) ++c->inst_grow_events;
     for (int k = 0; k < 2; ++k) {
         if ((r = c->inst_tile[k].ensure(T * 4)) != DVS_OK) return r;
         if ((r = c->inst_splat[k].ensure(T * 4)) != DVS_OK) return r;
     }
-    if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(T) * 4)) != DVS_OK) return r;
     c->inst_cap = c->inst_tile[0].bytes / 4;
     for (int k = 0; k < 2; ++k) {
         if (c->inst_tile[k].bytes / 4 < c->inst_cap) c->inst_cap = c->inst_tile[k].bytes / 4;
         if (c->inst_splat[k].bytes / 4 < c->inst_cap) c->inst_cap = c->inst_splat[k].bytes / 4;
     }
     if (c->inst_cap >= (1ull << 32)) c->inst_cap = (1ull << 32) - 1;       // instance offsets are 32-bit
-    if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(c->inst_cap) * 4)) != DVS_OK) return r;      // async: grids are sized for the capacity
     if ((r = c->fe_hist.ensure(dvs_fe_hist_words(c->inst_cap, c->max_views, 512) * 4)) != DVS_OK) return r;
     return DVS_OK;
 }
@@ -237,9 +235,8 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
         delete c;
         return nullptr;
     }
-    c->total_host[0] = c->total_host[1] = c->total_host[2] = c->total_host[3] = 0;   // [0] T  [1] arena overflows  [2] broken look-back chains (chained-scan sort)
+    c->total_host[0] = c->total_host[1] = c->total_host[2] = c->total_host[3] = 0;   // [0] T  [1] arena overflows
     if (const char* v = getenv("DVS_ASYNC")) c->async_T = v[0] == '1';
-    if (const char* v = getenv("DVS_FRONTEND")) c->fe_seg = !(v[0] == 'l' || v[0] == '0');
     if (ensure_frontend_arenas(c) != DVS_OK ||
         ensure_splat_arenas(c, max_splats * (size_t)max_views) != DVS_OK || ensure_image_arenas(c, max_w, max_h, max_views) != DVS_OK ||
         ensure_instance_arenas(c, (uint64_t)max_splats * 4 * (uint64_t)max_views) != DVS_OK) {
@@ -254,8 +251,8 @@ void dvs_destroy(dvs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     Buf* all[] = {&c->radii, &c->splat2d, &c->depth, &c->flags, &c->tiles_touched, &c->rect, &c->rect_sorted, &c->key[0], &c->key[1],
-                  &c->ids[0], &c->ids[1], &c->scan_blocks, &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
-                  &c->sort_scratch, &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows, &c->dcolor, &c->fe_state, &c->fe_hist};
+                  &c->ids[0], &c->ids[1], &c->inst_tile[0], &c->inst_tile[1], &c->inst_splat[0], &c->inst_splat[1],
+                  &c->tmp_keys, &c->tmp_vals, &c->ranges, &c->final_T, &c->n_contrib, &c->g_rows, &c->dcolor, &c->fe_state, &c->fe_hist, &c->ranges_canon};
     for (Buf* b : all) b->release();
     if (c->total_dev) (void)hipFree(c->total_dev);
     if (c->total_host) (void)hipHostFree(c->total_host);
@@ -293,12 +290,6 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         // forwards on this context (pinned copy, refreshed asynchronously): it grows the arenas ahead of need and reports an overflow
         // (T beyond the capacity: that view's outputs are invalid, nothing was written out of bounds) as DVS_ERR_CAPACITY, once.
         const uint64_t lastT = c->total_host[0], overflow = c->total_host[1];
-        if (c->total_host[2] != c->lookback_seen) {       // its own counter and message: growing the arena would not help
-            c->lookback_seen = c->total_host[2];
-            g_last_error = "dvs_raster_forward (async): the chained-scan sort (DVS_SORT_ONESWEEP=1) of an earlier forward ran out of look-back "
-                           "polls (preemption / profiler); that view's outputs are invalid — repeat it, or unset DVS_SORT_ONESWEEP.";
-            return DVS_ERR_STATE;
-        }
         if (overflow != c->overflow_seen) {
             c->overflow_seen = overflow;
             HIPCHECK(hipStreamSynchronize(st));
@@ -317,7 +308,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         T_dev = c->total_dev;
         T_expected = lastT > 0 ? lastT + lastT / 16 + 4096 : 0;      // grid size only: the kernels stride over whatever T turns out to be
     }
-    if (c->fe_seg) {
+    {
         // ---- the segmented front end (frontend.hip): every view is a segment of the sorts, workgroup b works for view b % V ----
         const int rect_fmt = tight ? DVS_FE_RECT_TIGHT : (tiles_x <= 255 && tiles_y <= 255) ? DVS_FE_RECT_U8 : DVS_FE_RECT_U16;
         // one memset: the key-range slots and super sums of the front end + the tile ranges behind them
@@ -386,46 +377,6 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         else HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), ranges_ptr(c), tiles * V, T_dev, T_expected, false));     // (cleared by the memset above)
         keys_written = write_keys;
         e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
-    } else {
-    // A2 preprocess: one lane per splat, all views
-    size_t e0 = tm.mark();
-    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
-                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
-                                       c->depth.as<float>(),
-                                       c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
-                                       c->ids[0].as<uint32_t>(), opts->shn_layout, c->rect.as<uint32_t>(), tight ? c->rect.as<uint32_t>() : nullptr));
-    size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
-    // A5 (low 32 key bits): depth sort over the (view, splat) elements, 4 x 8-bit LSD passes
-    int cur = 0;
-    HIPCHECK(dvs_launch_sort(st, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
-                             (uint64_t)nV, 0, 32, c->sort_scratch.as<uint32_t>(), nullptr, 0, (unsigned long long*)(c->total_dev + 2), &cur));
-    size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
-    // A3 scan in depth order (the one random gather of the binning stage: the tile rectangles)
-    HIPCHECK(dvs_launch_tile_scan(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect.as<uint32_t>(), c->rect_sorted.as<uint32_t>(),
-                                  c->scan_blocks.as<uint32_t>(), c->total_dev, c->async_T ? c->inst_cap : ~0ull, tight));
-    HIPCHECK(hipMemcpyAsync(c->total_host, c->total_dev, 32, hipMemcpyDeviceToHost, st));
-    size_t e3 = tm.mark(); tm.span("tile_scan", e2, e3);
-    if (!c->async_T) {
-        HIPCHECK(hipStreamSynchronize(st));
-        T = c->total_host[0];
-        if (T >= (1ull << 32)) { g_last_error = "dvs_raster_forward: more than 2^32 tile instances"; return DVS_ERR_CAPACITY; }
-        { int r = ensure_instance_arenas(c, T ? T : 1); if (r != DVS_OK) return r; }
-    }
-
-    // A4 duplicate
-    size_t e4 = tm.mark();
-    HIPCHECK(dvs_launch_duplicate(st, (int)nV, c->ids[cur].as<uint32_t>(), c->rect_sorted.as<uint32_t>(), c->scan_blocks.as<uint32_t>(),
-                                  tiles_x, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_cap, n, V, tiles, tight));
-    size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
-    // A5 (high key bits): sort by (view, tile) over the instances
-    const int tile_bits = bits_for((uint32_t)(tiles * V - 1));
-    HIPCHECK(dvs_launch_sort(st, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
-                             c->inst_splat[1].as<uint32_t>(), T, 0, tile_bits, c->sort_scratch.as<uint32_t>(), T_dev, T_expected,
-                             (unsigned long long*)(c->total_dev + 2), &icur));
-    size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
-    // A6 ranges
-    HIPCHECK(dvs_launch_tile_ranges(st, T, c->inst_tile[icur].as<uint32_t>(), ranges_ptr(c), tiles * V, T_dev, T_expected));
-    e7 = tm.mark(); tm.span("tile_ranges", e6, e7);
     }
     // A7 composite
     if (c->probe) { (void)probe_event(c, st); c->probe_kind.push_back(0); }
@@ -444,7 +395,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         if (c->live_lists && c->bwd_variant == DVS_BWD_TR) { c->live_splat = c->inst_splat[icur ^ 1].as<uint32_t>(); c->live_pos = c->inst_tile[icur ^ 1].as<uint32_t>(); }
         HIPCHECK(dvs_launch_render_fwd(st, W, H, tiles_x, tiles_y, V, ranges_ptr(c), c->inst_splat[icur].as<uint32_t>(),
                                        c->splat2d.as<float>(), bgs, out_rgb, c->final_T.as<float>(), c->n_contrib.as<uint32_t>(),
-                                       c->live_splat, c->live_pos, rec_masks, rec_cap, ranges_encoded));
+                                       c->live_splat, c->live_pos, rec_masks, rec_cap, ranges_encoded ? c->ranges_canon.as<uint32_t>() : nullptr));
     } else
         HIPCHECK(dvs_launch_render_fwd_blocks(st, W, H, tiles_x, tiles_y, ranges_ptr(c), c->inst_splat[icur].as<uint32_t>(),
                                               c->splat2d.as<float>(), cam->bg, out_rgb,
@@ -457,7 +408,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     s.flags = c->flags.as<uint32_t>();
     s.tiles_touched = c->tiles_touched.as<uint32_t>();
     s.sorted_tile = keys_written ? c->inst_tile[icur].as<uint32_t>() : nullptr; s.sorted_splat = c->inst_splat[icur].as<uint32_t>();
-    s.ranges = ranges_ptr(c); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
+    s.ranges = ranges_encoded ? c->ranges_canon.as<uint32_t>() : ranges_ptr(c); s.final_T = c->final_T.as<float>(); s.n_contrib = c->n_contrib.as<uint32_t>();
     s.num_rendered = c->async_T ? DVS_T_UNKNOWN : T; s.n = n; s.width = W; s.height = H; s.tiles_x = tiles_x; s.tiles_y = tiles_y;
     s._pad = 0;
     c->n_views = V;
@@ -706,11 +657,10 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
     int r;
     if ((r = c->tmp_keys.ensure(n * 4)) != DVS_OK) return r;
     if ((r = c->tmp_vals.ensure(n * 4)) != DVS_OK) return r;
-    if ((r = c->sort_scratch.ensure(dvs_sort_scratch_words(n) * 4)) != DVS_OK) return r;
     uint32_t* k[2] = {keys, c->tmp_keys.as<uint32_t>()};
     uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
     int cur = 0;
-    if (c->fe_seg) {
+    {
         if (n >= (1ull << 32)) { g_last_error = "dvs_sort_pairs_u32: n must be below 2^32"; return DVS_ERR_CAPACITY; }
         if ((r = c->fe_hist.ensure(dvs_fe_hist_words(n, 1, 512) * 4)) != DVS_OK) return r;
         const uint32_t part = dvs_fe_part_for(n);
@@ -718,9 +668,7 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
         c->fe_seg_n = -1;                                                    // (the forward's descriptors are gone)
         HIPCHECK(dvs_launch_seg_sort(st, 1, k[0], v[0], k[1], v[1], fe_seg_all(c), bit_lo, bit_hi - bit_lo, n, part, (uint32_t)(n / part) + 3u,
                                      c->fe_hist.as<uint32_t>(), fe_totals(c), 0u, &cur));
-    } else
-    HIPCHECK(dvs_launch_sort(st, k[0], v[0], k[1], v[1], n, bit_lo, bit_hi, c->sort_scratch.as<uint32_t>(), nullptr, 0,
-                             (unsigned long long*)(c->total_dev + 2), &cur));
+    }
     if (cur == 1) {
         HIPCHECK(hipMemcpyAsync(keys, k[1], n * 4, hipMemcpyDeviceToDevice, st));
         HIPCHECK(hipMemcpyAsync(vals, v[1], n * 4, hipMemcpyDeviceToDevice, st));
@@ -780,12 +728,6 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
     HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
     *T = c->total_host[0];
     c->st.num_rendered = *T;
-    if (c->total_host[2] != c->lookback_seen) {
-        c->lookback_seen = c->total_host[2];
-        g_last_error = "dvs_get_num_rendered: the chained-scan sort (DVS_SORT_ONESWEEP=1) ran out of look-back polls; the last forward's outputs "
-                       "are invalid — repeat it, or unset DVS_SORT_ONESWEEP.";
-        return DVS_ERR_STATE;
-    }
     if (c->total_host[1] != c->overflow_seen) {
         c->overflow_seen = c->total_host[1];
         (void)ensure_instance_arenas(c, *T + *T / 2);
@@ -793,6 +735,15 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
                        "invalid. The arena has been enlarged — repeat that view.";
         return DVS_ERR_CAPACITY;
     }
+    return DVS_OK;
+}
+
+int dvs_get_arena_info(dvs_ctx* c, uint64_t* cap, uint64_t* grows, uint64_t* last_T, uint64_t* overflows) {
+    if (!c) { g_last_error = "dvs_get_arena_info: null context"; return DVS_ERR_INVALID; }
+    if (cap) *cap = c->inst_cap;
+    if (grows) *grows = c->inst_grow_events;
+    if (last_T) *last_T = c->total_host[0];
+    if (overflows) *overflows = c->total_host[1];
     return DVS_OK;
 }
 

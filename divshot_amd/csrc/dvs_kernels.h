@@ -69,30 +69,7 @@ hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, co
                                   uint32_t tile_part, unsigned long long* total_dev, unsigned long long capacity, int stage, int tiles_x,
                                   uint32_t* inst_tile, uint32_t* inst_splat);
 
-// binning.hip
-// Number of uint32 scratch words dvs_launch_sort needs for up to n items.
-size_t dvs_sort_scratch_words(uint64_t n);
-// Stable LSD radix sort (8-bit digits) of (key, value) pairs over key bits [bit_lo, bit_hi). Default: three kernels per pass (per-
-// partition digit histogram, row scan of the histograms, scatter). DVS_SORT_ONESWEEP=1 selects the chained-scan form (one global
-// histogram kernel + one sweep kernel per pass; bit-exact, measured slower on MI355X; n < 2^30 only, larger sorts take the default).
-// Buffers 0 hold the input; *result_in = index (0 / 1) of the buffer pair with the result.
-// n_dev (nullable): the item count lives on the device (min(*n_dev, n) items are sorted; n bounds it) — no host round trip for T;
-// n_expected: grid hint for it. err_counter: device counter raised ONLY by the chained-scan form when a look-back runs out of polls
-// (outputs then invalid; the host reports it as a broken look-back chain, see dvs_api.cpp).
-hipError_t dvs_launch_sort(hipStream_t st, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, uint64_t n, int bit_lo, int bit_hi,
-                           uint32_t* scratch, const uint64_t* n_dev, uint64_t n_expected, unsigned long long* err_counter, int* result_in);
-// A3: gathers the tile rectangles (4 x u16 per splat, written by A2) into depth order, offsets over their areas. Writes block offsets
-// and total_dev[0] = T; total_dev[1] is incremented when T exceeds `capacity` (instances the arenas can hold).
-size_t dvs_scan_scratch_words(int n);
-// tight != 0 (DVS_TILES_TIGHT): rect / rect_sorted are the 16-B records {rectangle, tile mask} of k_preprocess_fwd, a splat's count is the
-// number of set mask bits (an all-ones mask = the whole rectangle)
-hipError_t dvs_launch_tile_scan(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect, uint32_t* rect_sorted,
-                                uint32_t* block_offsets, uint64_t* total_dev, uint64_t capacity, int tight);
-// A4: emit (tile id, splat id) for every tile of every splat, in depth-sorted order (streams ids + sorted rectangles).
-// n = n_views * n_per_view sorted elements whose values are global indices view * n_per_view + splat; tile ids are view * tiles_per_view + tile
-hipError_t dvs_launch_duplicate(hipStream_t st, int n, const uint32_t* sorted_ids, const uint32_t* rect_sorted,
-                                const uint32_t* block_offsets, int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, uint64_t capacity,
-                                int n_per_view, int n_views, int tiles_per_view, int tight);
+// frontend.hip, continued
 // A6: per-tile [start,end) from the sorted tile ids. T_dev (nullable): device-side count, T sizes the grid.
 hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles,
                                   const uint64_t* T_dev = nullptr, uint64_t T_expected = 0, bool clear = true /*false: the caller has zeroed `ranges`*/);
@@ -101,14 +78,14 @@ hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* so
                                   const float* depth, uint64_t* out_keys);
 
 // render.hip — one launch covers the tiles of all n_views views of a batch (view-major ranges / pixel arrays; bgs = [n_views][3])
-hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, uint32_t* ranges /*ranges_encoded != 0: arrives as
-                                 (~start, end) from the tile sort's last pass (0, 0 = empty) and leaves as (start, end)*/,
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges /*ranges_out != null: the
+                                 encoded form (~start, end) of the tile sort's last pass, (0, 0) = empty*/,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
                                  uint32_t* n_contrib, uint32_t* live_splat /*[T] out (or null): per tile, the entries whose alpha >= 1/255 ellipse
                                  reaches the tile, compacted in list order from ranges[tile].x*/, uint32_t* live_pos /*[T] out (or null): list
                                  position -> number of such entries before it in its tile*/,
                                  uint64_t* take_masks /*test hook (or null): [take_cap][4] zeroed by the caller — per list position and 8x8 quadrant, the pixels that took the entry*/,
-                                 uint64_t take_cap, int ranges_encoded = 0);
+                                 uint64_t take_cap, uint32_t* ranges_out = nullptr /*where k_render_fwd leaves (start, end) when `ranges` is encoded*/);
 // EXPERIMENT BUILDS ONLY (-DDVS_EXPERIMENT): the retired A8 kernels "reduce" and "mm". Declared weak: the release library does not
 // define it, dvs_set_backward_variant refuses those variants there.
 hipError_t dvs_launch_render_bwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,

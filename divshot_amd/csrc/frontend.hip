@@ -691,3 +691,60 @@ hipError_t dvs_launch_seg_init(hipStream_t st, int n, int V, uint32_t rows_per_v
     hipLaunchKernelGGL(k_seg_init, dim3(1), dim3(64), 0, st, n, V, rows_per_view, seg_all);
     return hipGetLastError();
 }
+
+// ---- A6 as its own kernel: only when k_render_fwd does not composite (experiment builds' per-block forward) or DVS_FE_NO_FUSE_A6=1;
+// normally the tile sort's last pass builds the ranges (k_seg_scatter) ---------------------------------------------------------------
+__global__ void __launch_bounds__(FE_BLOCK)
+k_tile_ranges(uint64_t T_host, const uint64_t* __restrict__ T_dev, const uint32_t* __restrict__ sorted_tile, uint2* __restrict__ ranges) {
+    const uint64_t T = T_dev ? (*T_dev < T_host ? *T_dev : T_host) : T_host;
+    // four consecutive instances per thread (one 16-B load + the two neighbours)
+    for (uint64_t q = (uint64_t)blockIdx.x * FE_BLOCK + threadIdx.x; q * 4 < T; q += (uint64_t)gridDim.x * FE_BLOCK) {
+        const uint64_t j0 = q * 4;
+        uint32_t t[6];                                  // t[0] = element j0 - 1, t[1..4] = j0 .. j0 + 3, t[5] = j0 + 4
+        if (j0 + 4 <= T) {
+            const uint4 v = reinterpret_cast<const uint4*>(sorted_tile)[q];
+            t[1] = v.x; t[2] = v.y; t[3] = v.z; t[4] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[1 + k] = j0 + k < T ? sorted_tile[j0 + k] : 0xFFFFFFFFu;
+        }
+        t[0] = j0 > 0 ? sorted_tile[j0 - 1] : 0xFFFFFFFFu;
+        t[5] = j0 + 4 < T ? sorted_tile[j0 + 4] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t j = j0 + k;
+            if (j < T) {
+                if (j == 0 || t[k] != t[k + 1]) ranges[t[k + 1]].x = (uint32_t)j;
+                if (j + 1 == T || t[k + 2] != t[k + 1]) ranges[t[k + 1]].y = (uint32_t)(j + 1);
+            }
+        }
+    }
+}
+
+hipError_t dvs_launch_tile_ranges(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, uint32_t* ranges, int tiles, const uint64_t* T_dev,
+                                  uint64_t T_expected, bool clear) {
+    hipError_t e = clear ? hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st) : hipSuccess;
+    if (e != hipSuccess) return e;
+    if (T == 0) return hipSuccess;
+    const uint64_t T_grid = (T_dev && T_expected > 0 && T_expected < T) ? T_expected : T;
+    const uint32_t nb = (uint32_t)((T_grid + 4 * FE_BLOCK - 1) / (4 * FE_BLOCK));
+    hipLaunchKernelGGL(k_tile_ranges, dim3(nb), dim3(FE_BLOCK), 0, st, T, T_dev, sorted_tile, (uint2*)ranges);
+    return hipGetLastError();
+}
+
+// ---- parity export: canonical 64-bit keys -------------------------------------------------------------------
+__global__ void __launch_bounds__(FE_BLOCK)
+k_export_keys(uint64_t T, const uint32_t* __restrict__ sorted_tile, const uint32_t* __restrict__ sorted_splat,
+              const float* __restrict__ depth, uint64_t* __restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * FE_BLOCK + threadIdx.x;
+    if (j >= T) return;
+    out[j] = ((uint64_t)sorted_tile[j] << 32) | (uint64_t)__float_as_uint(depth[sorted_splat[j]]);
+}
+
+hipError_t dvs_launch_export_keys(hipStream_t st, uint64_t T, const uint32_t* sorted_tile, const uint32_t* sorted_splat,
+                                  const float* depth, uint64_t* out_keys) {
+    if (T == 0) return hipSuccess;
+    const uint32_t nb = (uint32_t)((T + FE_BLOCK - 1) / FE_BLOCK);
+    hipLaunchKernelGGL(k_export_keys, dim3(nb), dim3(FE_BLOCK), 0, st, T, sorted_tile, sorted_splat, depth, out_keys);
+    return hipGetLastError();
+}

@@ -133,7 +133,8 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 template <bool RECORD>
 __global__ void __launch_bounds__(RB)
 k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_load_bg() */, int W, int H, int tiles_x, int tiles_per_view,
-             int num_tiles /* = views * tiles_per_view */, uint2* __restrict__ ranges, int ranges_encoded,
+             int num_tiles /* = views * tiles_per_view */, const uint2* __restrict__ ranges, uint2* __restrict__ ranges_out /*null, or: `ranges` is the
+             encoded form the tile sort's last pass leaves, and the (start, end) pairs go here*/,
              const uint32_t* __restrict__ sorted_splat, const float4* __restrict__ splat2d,
              float* __restrict__ out_color /*[views,3,H,W]*/, float* __restrict__ final_T /*[views,H,W]*/, uint32_t* __restrict__ n_contrib,
              uint32_t* __restrict__ live_splat /*[T] per tile, from ranges[tile].x: the entries that reach the tile, in list order*/,
@@ -156,12 +157,12 @@ k_render_fwd(ViewBg bg_arg /* MUST stay the first parameter: read through dvs_lo
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     uint2 range = ranges[tile_g];
-    if (ranges_encoded) {
+    if (ranges_out) {
         // A6 is fused into the tile sort's last pass (frontend.hip k_seg_scatter): the entry arrives as (~start, end), (0, 0) = no
-        // instance. Decode it and leave the canonical pair for A8 and the exported state (every wave has read before lane 0 rewrites).
+        // instance. Decode it and leave the canonical pair — in its own array: no barrier between the waves' reads and this store — for
+        // A8 and the exported state.
         range.x = range.y ? ~range.x : 0u;
-        __syncthreads();
-        if (threadIdx.x == 0) ranges[tile_g] = range;
+        if (threadIdx.x == 0) ranges_out[tile_g] = range;
     }
     const int total = (int)(range.y - range.x);
     // Pixel state that decides control flow lives in wave masks (scalar registers): `notdone` = pixels still compositing. A visit forms
@@ -634,9 +635,9 @@ k_render_bwd_mm(int W, int H, int tiles_x, int num_tiles, const uint2* __restric
 
 // ---- launchers -----------------------------------------------------------------------------------------
 
-hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, uint32_t* ranges,
+hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int tiles_y, int n_views, const uint32_t* ranges,
                                  const uint32_t* sorted_splat, const float* splat2d, const float* bgs, float* out_color, float* final_T,
-                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos, uint64_t* take_masks, uint64_t take_cap, int ranges_encoded) {
+                                 uint32_t* n_contrib, uint32_t* live_splat, uint32_t* live_pos, uint64_t* take_masks, uint64_t take_cap, uint32_t* ranges_out) {
     const int tiles_pv = tiles_x * tiles_y, num_tiles = tiles_pv * n_views;
     if (num_tiles <= 0) return hipSuccess;
     const int grid = ((num_tiles + 7) >> 3) << 3;
@@ -645,10 +646,10 @@ hipError_t dvs_launch_render_fwd(hipStream_t st, int W, int H, int tiles_x, int 
 #endif
     if (take_masks)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                           (uint2*)ranges, ranges_encoded, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, take_masks, take_cap DVS_DBG_PASS(dbg));
+                           (const uint2*)ranges, (uint2*)ranges_out, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, take_masks, take_cap DVS_DBG_PASS(dbg));
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(RB), 0, st, make_view_bg(n_views, bgs), W, H, tiles_x, tiles_pv, num_tiles,
-                           (uint2*)ranges, ranges_encoded, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, (uint64_t*)nullptr, (uint64_t)0 DVS_DBG_PASS(dbg));
+                           (const uint2*)ranges, (uint2*)ranges_out, sorted_splat, (const float4*)splat2d, out_color, final_T, n_contrib, live_splat, live_pos, (uint64_t*)nullptr, (uint64_t)0 DVS_DBG_PASS(dbg));
     return hipGetLastError();
 }
 

@@ -442,7 +442,13 @@ void GaussianTrainerScene::Impl::densify(int it) {
         DVS_OR_THROW(dvs_densify_apply(stream, n, d_action, d_offsets, &prm, set == 0 ? 0 : 1, s6, dst, (int)new_n));
         for (int g = 0; g < 6; ++g) std::swap(src[g], dst[g]);
     }
-    if (cfg.verbose) logf_("densify @%d: %d -> %llu splats", it, n, (unsigned long long)new_n);
+    if (cfg.verbose) {
+        logf_("densify @%d: %d -> %llu splats", it, n, (unsigned long long)new_n);
+        uint64_t cap_ = 0, grows_ = 0, lastT_ = 0, over_ = 0;        // the rasterizer's instance arena at this point (HBM pressure of big scenes)
+        if (dvs_get_arena_info(ctx, &cap_, &grows_, &lastT_, &over_) == DVS_OK)
+            logf_("raster @%d: T = %llu tile instances in the last pass, instance arena %llu (enlarged %llu times), overflowed forwards %llu",
+                  it, (unsigned long long)lastT_, (unsigned long long)cap_, (unsigned long long)grows_, (unsigned long long)over_);
+    }
     n = (int)new_n;
     HIP_OR_THROW(hipMemsetAsync(d_grad[P_SHN], 0, dev_floats_for(P_SHN, cap) * sizeof(float), stream));   // pad lanes of the new last tile
     reset_stats();

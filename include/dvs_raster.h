@@ -254,6 +254,10 @@ int dvs_get_view_state(dvs_ctx* ctx, int view, dvs_fwd_state* state);
 #define DVS_T_UNKNOWN (~0ull)
 int dvs_set_async(dvs_ctx* ctx, int enable);
 int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
+/* The instance arena of the context (host bookkeeping, no synchronisation): how many tile instances it holds now, how often it has been
+ * enlarged since dvs_create, the T of the last forward the host knows (synchronous forward: that forward's; asynchronous: an earlier
+ * one's) and how many forwards overflowed it (each of those was reported once as DVS_ERR_CAPACITY). Any pointer may be NULL. */
+int dvs_get_arena_info(dvs_ctx* ctx, uint64_t* instance_capacity, uint64_t* grow_events, uint64_t* last_num_rendered, uint64_t* overflows);
 
 /* TEST HOOK of the parity suite. While take_masks is non-NULL, every single-view synchronous forward on the context (default A7 kernel)
  * also records ITS OWN threshold decisions: take_masks[4 * j + q] (device memory, 8-byte aligned, capacity_instances * 4 words, zeroed by
