@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of builds of libdvsraster.so on the default bench step: ROUNDS=3 tools/r3_ab.sh libA.so libB.so ...
+# same-box A/B of builds of libdvsraster.so on the default bench step: ROUNDS=3 tools/lib_ab.sh libA.so libB.so ...
 cd "$(dirname "$0")/.."
 R=${ROUNDS:-3}
 for i in $(seq 1 $R); do

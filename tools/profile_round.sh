@@ -13,6 +13,7 @@ mkdir -p gpurun_out
 rm -rf gpurun_out/prof_${TAG}
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} -o p -- python $R/bench.py --no-cpu-baseline --steps 50 --warmup 5 --profile-iters 0 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_bench.stderr )
 python tools/rocpd_summary.py gpurun_out/prof_${TAG}/p_results.db > gpurun_out/${TAG}_kernel_stats.txt 2>&1
+python tools/rocpd_summary.py gpurun_out/prof_${TAG}/p_results.db --by-grid > gpurun_out/${TAG}_kernel_stats_by_grid.txt 2>&1
 ( cd /tmp && bash $R/tools/pmc.sh ${TAG}_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE ) > /dev/null 2>&1
 ( cd /tmp && bash $R/tools/pmc.sh ${TAG}_fetch FETCH_SIZE ) > /dev/null 2>&1
 ( cd /tmp && bash $R/tools/pmc.sh ${TAG}_write WRITE_SIZE ) > /dev/null 2>&1
@@ -21,6 +22,6 @@ python tools/make_traffic_json.py gpurun_out/pmc_${TAG}_fetch.txt gpurun_out/pmc
 cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_traffic.json; cp gpurun_out/pmc_${TAG}_sq.txt profiles/${TAG}_pmc_sq.txt
 python bench.py > gpurun_out/${TAG}_bench.json 2>> gpurun_out/${TAG}_bench.stderr
 python bench.py --mode pipelined --no-cpu-baseline --steps 100 > gpurun_out/${TAG}_bench_pipelined.json 2>> gpurun_out/${TAG}_bench.stderr
-python bench.py --workload C5 --global-views 4 --no-cpu-baseline --steps 50 --warmup 5 > gpurun_out/${TAG}_bench_c5.json 2>> gpurun_out/${TAG}_bench.stderr
+python bench.py --workload C5 --global-views ${C5_VIEWS:-4} --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/${TAG}_bench_c5.json 2>> gpurun_out/${TAG}_bench.stderr
 head -c 400 gpurun_out/${TAG}_bench.json; echo
 head -16 gpurun_out/${TAG}_kernel_stats.txt
