@@ -908,7 +908,7 @@ def test_project_chunks_equal_project(gpu_device):
 def test_depth_sort_digit_width_follows_the_key_range(gpu_device, oracle_mod, zmax):
     """The depth sort takes three passes whatever the scene: its digit is ceil(bits(max key - min key) / 3) bits wide, chosen per view
     on the device (frontend.hip). Depths spread log-uniformly from the near plane to zmax put the range at 23 + log2(zmax / 0.25) bits:
-    9-bit digits (re-ordered in LDS) up to a depth ratio of 2^16, then 10-bit digits scattered straight from registers (11-bit digits
+    9-bit digits (re-ordered in LDS) up to a depth ratio of 2^12 from the 0.2 near plane, then 10-bit digits scattered straight from registers (11-bit digits
     — all 31 key bits — cannot be reached through the projection: beyond z ~ 1e19 its squares overflow and the splat is culled; the
     static-digit path of the same kernel is covered by test_sort_pairs). Bins (radii, (tile | depth) keys, values, ranges) bit-exact against the oracle's std::stable_sort, with many
     exactly equal depths (ties resolve by splat id) and a fifth of the splats culled (they leave in the first pass)."""
@@ -934,7 +934,7 @@ def test_depth_sort_digit_width_follows_the_key_range(gpu_device, oracle_mod, zm
     vis = got["radii"] > 0
     assert 0.5 * n < vis.sum() < 0.9 * n
     rbits = int(got["depth"][vis].view(np.uint32).max() - got["depth"][vis].view(np.uint32).min()).bit_length()
-    assert rbits >= (28 if zmax > 1e8 else 27 if zmax > 1e3 else 20) and (rbits <= 27) == (zmax < 1e8), rbits      # 9-bit digits up to 27 bits, 10-bit beyond
+    assert rbits >= (28 if zmax > 1e3 else 20) and (rbits <= 27) == (zmax < 1e3), rbits      # 9-bit digits up to 27 bits (z up to ~800), 10-bit beyond
     assert np.array_equal(got["radii"], o.get("radii")) and np.array_equal(got["tiles_touched"], o.get("tiles_touched"))
     assert np.array_equal(keys, o.get("keys")) and np.array_equal(got["vals"], o.get("vals")) and np.array_equal(got["ranges"], o.get("ranges"))
     ok = ~o.get("fragile").astype(bool)
