@@ -148,6 +148,7 @@ void timing_collect(dvs_ctx* c, bool append) {
     }
 }
 
+bool fe_no_key16() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_KEY16"); return e && e[0] == '1'; }(); return v; }      // (A/B aid)
 bool fe_no_fuse() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_FUSE_A6"); return e && e[0] == '1'; }(); return v; }      // (A/B aid)
 uint32_t* ranges_ptr(dvs_ctx* c) { return (uint32_t*)((char*)c->ranges.p + c->fe_zero_bytes); }
 uint32_t* fe_kred(dvs_ctx* c) { return (uint32_t*)c->ranges.p; }
@@ -350,13 +351,15 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
             if (T >= (1ull << 32)) { g_last_error = "dvs_raster_forward: more than 2^32 tile instances"; return DVS_ERR_CAPACITY; }
             { int r = ensure_instance_arenas(c, T ? T : 1); if (r != DVS_OK) return r; }
         }
-        // A4 duplicate, view by view
+        // A4 duplicate, view by view. Tile ids inside a view fit 16 bits up to 65 536 tiles (4096 x 4096 pixels): A4, the first
+        // histogram and the first tile pass then move 2 B per instance for them instead of 4.
+        const int key16 = (tiles <= 65536 && !fe_no_key16()) ? 1 : 0;
         size_t e4 = tm.mark();
         if (n > 0)
             HIPCHECK(dvs_launch_seg_binning(st, n, V, rect_fmt, fe_seg_vis(c), fe_seg_tile(c), c->ids[1].as<uint32_t>(), c->rect.as<uint32_t>(),
                                             c->rect_sorted.as<uint32_t>(), fe_block_sums(c), fe_super(c), fe_superexcl(c), tile_part,
                                             (unsigned long long*)c->total_dev, c->inst_cap, 1, tiles_x, c->inst_tile[0].as<uint32_t>(),
-                                            c->inst_splat[0].as<uint32_t>()));
+                                            c->inst_splat[0].as<uint32_t>(), key16));
         size_t e5 = tm.mark(); tm.span("duplicate", e4, e5);
         // A5 (high key bits): every view's instances by tile id; the last pass hands out view * tiles + tile
         // A6 rides on the last pass (a range boundary is where the scattered tile id changes) whenever k_render_fwd composites (it decodes
@@ -370,7 +373,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
             HIPCHECK(dvs_launch_seg_sort(st, V, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
                                          c->inst_splat[1].as<uint32_t>(), fe_seg_tile(c), 0, tiles > 1 ? bits_for((uint32_t)(tiles - 1)) : 1,
                                          c->async_T ? (T_expected ? T_expected : c->inst_cap) : T, tile_part, nbtot, c->fe_hist.as<uint32_t>(), fe_totals(c),
-                                         (uint32_t)tiles, &icur, fuse_a6 ? ranges_ptr(c) : nullptr, write_keys ? 1 : 0));
+                                         (uint32_t)tiles, &icur, fuse_a6 ? ranges_ptr(c) : nullptr, write_keys ? 1 : 0, key16));
         }
         size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
         if (fuse_a6) ranges_encoded = n > 0 ? 1 : 0;

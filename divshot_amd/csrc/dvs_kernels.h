@@ -62,12 +62,12 @@ hipError_t dvs_launch_depth_sort(hipStream_t st, int n, int V, uint32_t* keys0, 
 hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
                                uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
                                int* result_in, uint32_t* ranges_enc = nullptr /*A6 fused into the last pass: tile ranges as (~start, end), see k_seg_scatter*/,
-                               int write_last_keys = 1);
+                               int write_last_keys = 1, int first_keys16 = 0 /*keys0 holds 16-bit keys (A4's tile ids)*/);
 // stage 0 = A3 (tile counts in depth order, block / super sums) + the views' instance ranges (seg_tile, total_dev); stage 1 = A4
 hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, const DvsSeg* seg_vis, DvsSeg* seg_tile, const uint32_t* sorted_ids,
                                   const uint32_t* rect, uint32_t* rect_sorted, uint32_t* block_sums, unsigned long long* super, uint32_t* superexcl,
                                   uint32_t tile_part, unsigned long long* total_dev, unsigned long long capacity, int stage, int tiles_x,
-                                  uint32_t* inst_tile, uint32_t* inst_splat);
+                                  uint32_t* inst_tile, uint32_t* inst_splat, int key16 = 0 /*A4 writes the tile ids as 16-bit words*/);
 
 // frontend.hip, continued
 // A6: per-tile [start,end) from the sorted tile ids. T_dev (nullable): device-side count, T sizes the grid.

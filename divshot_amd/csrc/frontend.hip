@@ -82,7 +82,7 @@ __device__ __forceinline__ uint32_t fe_block_excl_scan(uint32_t v, uint32_t* tmp
 template <int ITEMS>
 __global__ void __launch_bounds__(FE_BLOCK)
 k_seg_hist(const uint32_t* __restrict__ keys, DvsSeg* __restrict__ seg, int V, int adaptive, int pass, int shift_s, int bits_s, int cull,
-           uint32_t* __restrict__ hist, uint32_t nbtot, const uint32_t* __restrict__ kred) {
+           uint32_t* __restrict__ hist, uint32_t nbtot, const uint32_t* __restrict__ kred, int key16 /*the keys are 16-bit (A4's tile ids)*/) {
     __shared__ uint32_t h[FE_MAXBINS];
     constexpr uint32_t PART = FE_BLOCK * ITEMS;
     const uint32_t lane = fe_lane(), wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -113,9 +113,15 @@ k_seg_hist(const uint32_t* __restrict__ keys, DvsSeg* __restrict__ seg, int V, i
         const uint32_t wb = p * PART + wave * (64 * ITEMS);
         uint32_t kreg[ITEMS];
         const uint32_t* const kin = keys + s_base;
+        const uint16_t* const kin16 = reinterpret_cast<const uint16_t*>(keys) + s_base;
         const uint32_t i0 = wb + lane, ilast = s_count - 1u;
+        if (key16) {
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; kreg[r] = kin[idx < ilast ? idx : ilast]; }
+            for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; kreg[r] = kin16[idx < ilast ? idx : ilast]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; kreg[r] = kin[idx < ilast ? idx : ilast]; }
+        }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const bool valid = i0 + (uint32_t)r * 64 <= ilast && !(cull && kreg[r] == FE_CULLED);
@@ -180,6 +186,7 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
               (same base / pstart / sub / bits, count = the elements that survived the culling)*/,
               int V, int adaptive, int pass, int shift_s, int bits_s, int cull, uint32_t key_add_per_view,
               const uint32_t* __restrict__ hist, uint32_t nbtot, const uint32_t* __restrict__ totals,
+              int key16 /*keys_in holds 16-bit keys (the tile ids A4 wrote: 2 B per instance instead of 4 through A4, the histogram and this pass)*/,
               uint32_t* __restrict__ ranges_enc /*null, or (last pass of the tile sort: A6 fused) the tile ranges [V * tiles][2], zeroed: every run of equal
               keys in a partition's output raises word 0 to ~(first position) and word 1 to (last position + 1) with atomic max — a tile's runs
               from all partitions leave (~start, end); k_render_fwd turns that into (start, end)*/) {
@@ -204,6 +211,7 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
     const uint32_t* const vtot = totals + (size_t)view * FE_MAXBINS;
     // uniform segment bases + 32-bit lane offsets: scalar base / vector offset addressing, no 64-bit address per load
     const uint32_t* const kin = keys_in + S.base;
+    const uint16_t* const kin16 = reinterpret_cast<const uint16_t*>(keys_in) + S.base;
     const uint32_t* const vin = vals_in ? vals_in + S.base : nullptr;
     uint32_t* const kout = keys_out ? keys_out + S.base : nullptr;
     uint32_t* const vout = vals_out + S.base;
@@ -218,8 +226,13 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
     constexpr bool EARLY = ITEMS <= 8;
     auto request = [&](uint32_t p) {
         const uint32_t i0 = p * PART + wave * (64 * ITEMS) + lane;
+        if (key16) {
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; key[r] = kin[idx < ilast ? idx : ilast]; }
+            for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; key[r] = kin16[idx < ilast ? idx : ilast]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; key[r] = kin[idx < ilast ? idx : ilast]; }
+        }
         if (vin) {
 #pragma unroll
             for (int r = 0; r < ITEMS; ++r) { const uint32_t idx = i0 + (uint32_t)r * 64; val[r] = vin[idx < ilast ? idx : ilast]; }
@@ -377,20 +390,20 @@ struct FeSortLaunch {
 
 static hipError_t fe_launch_pass(const FeSortLaunch& L, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, DvsSeg* seg_in,
                                  DvsSeg* seg_out, int adaptive, int pass, int shift, int bits, int cull, uint32_t key_add_per_view,
-                                 const uint32_t* kred, uint32_t* ranges_enc = nullptr) {
+                                 const uint32_t* kred, uint32_t* ranges_enc = nullptr, int key16 = 0) {
     const dim3 grid(L.grid_per_view * (uint32_t)L.V), blk(FE_BLOCK);
     const int maxbins = adaptive ? FE_MAXBINS : (1 << bits);
     const dim3 rgrid((uint32_t)((maxbins + FE_WAVES - 1) / FE_WAVES) * (uint32_t)L.V);
     if (L.items == 8) {
-        hipLaunchKernelGGL(k_seg_hist<8>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred);
+        hipLaunchKernelGGL(k_seg_hist<8>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred, key16);
         hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * 8), L.totals);
         hipLaunchKernelGGL(k_seg_scatter<8>, grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits,
-                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, ranges_enc);
+                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, key16, ranges_enc);
     } else {
-        hipLaunchKernelGGL(k_seg_hist<16>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred);
+        hipLaunchKernelGGL(k_seg_hist<16>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred, key16);
         hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * 16), L.totals);
         hipLaunchKernelGGL(k_seg_scatter<16>, grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits,
-                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, ranges_enc);
+                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, key16, ranges_enc);
     }
     return hipGetLastError();
 }
@@ -433,7 +446,7 @@ uint32_t dvs_fe_part_for(uint64_t grid_elems) { return (uint32_t)FE_BLOCK * (uin
 
 hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
                                uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
-                               int* result_in, uint32_t* ranges_enc, int write_last_keys) {
+                               int* result_in, uint32_t* ranges_enc, int write_last_keys, int first_keys16) {
     if (result_in) *result_in = 0;
     if (V <= 0 || bits <= 0) return hipSuccess;
     int npass, widths[4];
@@ -452,7 +465,7 @@ hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t*
         const bool last = k == npass - 1;
         // the last pass of the tile sort builds the tile ranges (A6) and may skip the keys: nothing reads them but the exported state
         hipError_t e = fe_launch_pass(L, kk[c], vv[c], (last && !write_last_keys) ? nullptr : kk[c ^ 1], vv[c ^ 1], seg, nullptr, 0, k, shift, widths[k], 0,
-                                      last ? key_add_per_view : 0u, nullptr, last ? ranges_enc : nullptr);
+                                      last ? key_add_per_view : 0u, nullptr, last ? ranges_enc : nullptr, (k == 0 && first_keys16) ? 1 : 0);
         if (e != hipSuccess) return e;
         shift += widths[k];
         c ^= 1;
@@ -605,7 +618,7 @@ __global__ void __launch_bounds__(FE_BLOCK)
 k_seg_duplicate(int n, int V, uint32_t nbv, uint32_t nsb, const DvsSeg* __restrict__ seg_vis, const DvsSeg* __restrict__ seg_tile,
                 const uint32_t* __restrict__ sorted_ids, const typename FeRect<FMT>::T* __restrict__ rect_sorted,
                 const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ superexcl, int tiles_x,
-                uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat, unsigned long long capacity) {
+                uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat, unsigned long long capacity, int key16 /*tile ids as 16-bit words*/) {
     __shared__ uint32_t tmp[FE_WAVES];
     __shared__ uint32_t s_pre[FE_BLOCK + 1];      // exclusive offset of the thread's first instance inside the block; [FE_BLOCK] = block total
     __shared__ uint32_t s_id[FE_BLOCK];
@@ -654,7 +667,8 @@ k_seg_duplicate(int n, int V, uint32_t nbv, uint32_t nsb, const DvsSeg* __restri
         if (rem < 0) { --q; rem += (int32_t)w; } else if (rem >= (int32_t)w) { ++q; rem -= (int32_t)w; }
         const unsigned long long g = gbase + k;
         if (g < capacity) {
-            inst_tile[g] = s_tile[src] + q * (uint32_t)tiles_x + (uint32_t)rem;
+            const uint32_t tile = s_tile[src] + q * (uint32_t)tiles_x + (uint32_t)rem;
+            if (key16) reinterpret_cast<uint16_t*>(inst_tile)[g] = (uint16_t)tile; else inst_tile[g] = tile;
             inst_splat[g] = s_id[src];
         }
     }
@@ -663,7 +677,7 @@ k_seg_duplicate(int n, int V, uint32_t nbv, uint32_t nsb, const DvsSeg* __restri
 hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, const DvsSeg* seg_vis, DvsSeg* seg_tile, const uint32_t* sorted_ids,
                                   const uint32_t* rect, uint32_t* rect_sorted, uint32_t* block_sums, unsigned long long* super, uint32_t* superexcl,
                                   uint32_t tile_part, unsigned long long* total_dev, unsigned long long capacity, int stage /*0: A3 + totals, 1: A4*/,
-                                  int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat) {
+                                  int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, int key16) {
     if (n <= 0 || V <= 0) return hipSuccess;
     const uint32_t nbv = (uint32_t)((n + FE_BLOCK - 1) / FE_BLOCK), nsb = (nbv + 255u) / 256u;
     const dim3 grid(nbv * (uint32_t)V), grid3(((nbv + 3u) / 4u) * (uint32_t)V), blk(FE_BLOCK);
@@ -674,7 +688,7 @@ hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, co
         hipLaunchKernelGGL(k_seg_totals, dim3(1), dim3(1024), 0, st, V, nsb, (const unsigned long long*)super, superexcl, seg_tile, tile_part, total_dev, capacity);
     } else {
 #define FE_A4(F) hipLaunchKernelGGL(k_seg_duplicate<F>, grid, blk, 0, st, n, V, nbv, nsb, seg_vis, (const DvsSeg*)seg_tile, sorted_ids, (const FeRect<F>::T*)rect_sorted, \
-                                    (const uint32_t*)block_sums, (const uint32_t*)superexcl, tiles_x, inst_tile, inst_splat, capacity)
+                                    (const uint32_t*)block_sums, (const uint32_t*)superexcl, tiles_x, inst_tile, inst_splat, capacity, key16)
         if (rect_fmt == DVS_FE_RECT_U8) FE_A4(DVS_FE_RECT_U8); else if (rect_fmt == DVS_FE_RECT_U16) FE_A4(DVS_FE_RECT_U16); else FE_A4(DVS_FE_RECT_TIGHT);
 #undef FE_A4
     }
