@@ -148,8 +148,8 @@ void timing_collect(dvs_ctx* c, bool append) {
     }
 }
 
-bool fe_no_key16() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_KEY16"); return e && e[0] == '1'; }(); return v; }      // (A/B aid)
-bool fe_no_fuse() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_FUSE_A6"); return e && e[0] == '1'; }(); return v; }      // (A/B aid)
+bool fe_no_key16() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_KEY16"); return e && e[0] == '1'; }(); return v; }      // cross-check switch (tests): 32-bit tile ids
+bool fe_no_fuse() { static const bool v = [] { const char* e = getenv("DVS_FE_NO_FUSE_A6"); return e && e[0] == '1'; }(); return v; }      // cross-check switch (tests): A6 as its own kernel
 uint32_t* ranges_ptr(dvs_ctx* c) { return (uint32_t*)((char*)c->ranges.p + c->fe_zero_bytes); }
 uint32_t* fe_kred(dvs_ctx* c) { return (uint32_t*)c->ranges.p; }
 unsigned long long* fe_super(dvs_ctx* c) { return (unsigned long long*)((char*)c->ranges.p + (size_t)DVS_FE_KRED_WORDS * 4); }

@@ -370,8 +370,6 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
 }
 
 static inline int fe_items_for(uint64_t n_total) {
-    static const int forced = [] { const char* e = getenv("DVS_FE_ITEMS"); return e ? atoi(e) : 0; }();        // (measurement aid: 8 / 16)
-    if (forced == 8 || forced == 16) return forced;
     return n_total <= 1500000ull ? 8 : 16;
 }
 

@@ -945,7 +945,8 @@ def test_depth_sort_digit_width_follows_the_key_range(gpu_device, oracle_mod, zm
 def test_tile_ranges_fused_into_the_sort_equal_the_separate_kernel(gpu_device):
     """A6 rides on the tile sort's last pass (every run of equal tile ids raises (~start, end) with atomic max, k_render_fwd decodes); with
     DVS_FE_NO_FUSE_A6=1 the separate boundary kernel of rounds 1-4 runs instead. Same ranges, same lists, same image — one view and a
-    batch, synchronous and asynchronous (the asynchronous fused forward does not even write the sorted tile ids)."""
+    batch, synchronous and asynchronous (the asynchronous fused forward does not even write the sorted tile ids). Third run:
+    DVS_FE_NO_KEY16=1 — A4 writes 32-bit tile ids instead of 16-bit ones (the form views of more than 65 536 tiles take)."""
     import subprocess, sys
     code = r"""
 import os, sys, numpy as np, torch
@@ -967,20 +968,22 @@ np.save(sys.argv[1], np.array([out], dtype=object), allow_pickle=True)
 """
     import tempfile
     res = {}
-    for tag, env_extra in (("fused", {}), ("separate", {"DVS_FE_NO_FUSE_A6": "1"})):
+    for tag, env_extra in (("fused", {}), ("separate", {"DVS_FE_NO_FUSE_A6": "1"}), ("keys32", {"DVS_FE_NO_KEY16": "1"})):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "o.npy")
             env = dict(os.environ, DVS_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), **env_extra)
-            env.pop("DVS_FE_NO_FUSE_A6", None) if tag == "fused" else None
+            for k in ("DVS_FE_NO_FUSE_A6", "DVS_FE_NO_KEY16"):
+                if k not in env_extra: env.pop(k, None)
             p = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env)
             assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
             res[tag] = np.load(path, allow_pickle=True)[0]
     for asy in (False, True):
-        f, s_ = res["fused"][asy], res["separate"][asy]
+      for other in ("separate", "keys32"):
+        f, s_ = res["fused"][asy], res[other][asy]
         assert np.array_equal(f[0], s_[0]) and np.array_equal(f[2], s_[2])
         for a, b in [(f[1], s_[1])] + list(zip(f[3], s_[3])):
             for k in ("vals", "sorted_tile", "ranges", "n_contrib"):
-                assert np.array_equal(a[k], b[k]), (asy, k)
+                assert np.array_equal(a[k], b[k]), (other, asy, k)
         # synchronous and asynchronous forwards agree as well
         for k in ("vals", "sorted_tile", "ranges", "n_contrib"):
             assert np.array_equal(res["fused"][False][1][k], res["fused"][True][1][k]), k
