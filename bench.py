@@ -24,6 +24,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument); the
+# variable is read when the HSA runtime starts, i.e. before anything below touches HIP
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOADS = {
     # name: (n, W, H, sh_degree, scale_log_offset)

@@ -37,6 +37,7 @@ template <class F> static F sym(void* h, const char* name, bool required = true)
 }
 
 int main(int argc, const char* argv[]) {
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC for RCCL between the ranks' processes; read when the HSA runtime starts (first HIP call)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--help" || a == "-h") {
