@@ -605,12 +605,24 @@ __device__ __forceinline__ uint32_t fe_nth_set_bit64(uint32_t lo, uint32_t hi, u
 }
 
 // ---- A4: duplicate with keys, in depth order, view by view ------------------------------------------------------------------------------
-// Workgroup (view, block) streams (splat index, rectangle) of its 256 elements and emits their instances at
+// Workgroup (view, block pair) streams (splat index, rectangle) of its 2 x 256 elements and emits their instances at
 // seg_tile[view].base + superexcl[view][block / 256] + sum of the block sums since that super block + the in-block offset.
-// Every wave emits the instances of its own 64 splats cooperatively: output slot k of the wave finds its splat by a binary search over the
-// 64 exclusive offsets (LDS) and its tile from the slot's index inside the rectangle (row-major), so that a store instruction covers 64
-// consecutive instances whatever the rectangle sizes are. Keys are tile ids INSIDE the view; values are view * n + splat.
-// Instances beyond `capacity` are not written (k_seg_totals has raised the overflow counter).
+// Every wave emits the instances of its own 64 splats cooperatively, 64 consecutive output slots at a time: the splats whose first
+// instance falls into the 64 slots leave their lane number there (LDS, one word per slot), a DPP max-scan carries it to the slots behind,
+// and the slot's tile follows from its index inside the rectangle (row-major) — a store instruction covers 64 consecutive instances
+// whatever the rectangle sizes are. (Rounds 3-5a found a slot's splat by a binary search over the exclusive offsets: six dependent LDS
+// round trips per 64 instances in a kernel that is one latency chain per workgroup.) Everything the chain needs from global memory — both
+// blocks' elements, the block sums, the view's start, the super block's prefix — is requested before the first scan.
+// Keys are tile ids INSIDE the view; values are view * n + splat. Instances beyond `capacity` are not written (k_seg_totals has raised
+// the overflow counter).
+__device__ __forceinline__ uint32_t fe_wave_incl_max(uint32_t v) {
+#define FE_DPP_MAX(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false); v = v > o_ ? v : o_; }
+    FE_DPP_MAX(0x111, 0xF); FE_DPP_MAX(0x112, 0xF); FE_DPP_MAX(0x114, 0xF); FE_DPP_MAX(0x118, 0xF);   // row_shr:1, 2, 4, 8
+    FE_DPP_MAX(0x142, 0xA);                                                                              // row_bcast:15 -> rows 1, 3
+    FE_DPP_MAX(0x143, 0xC);                                                                              // row_bcast:31 -> rows 2, 3
+#undef FE_DPP_MAX
+    return v;
+}
 template <int FMT>
 __global__ void __launch_bounds__(FE_BLOCK)
 k_seg_duplicate(int n, int V, uint32_t nbv, uint32_t nsb, const DvsSeg* __restrict__ seg_vis, const DvsSeg* __restrict__ seg_tile,
@@ -618,57 +630,79 @@ k_seg_duplicate(int n, int V, uint32_t nbv, uint32_t nsb, const DvsSeg* __restri
                 const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ superexcl, int tiles_x,
                 uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_splat, unsigned long long capacity, int key16 /*tile ids as 16-bit words*/) {
     __shared__ uint32_t tmp[FE_WAVES];
-    __shared__ uint32_t s_pre[FE_BLOCK + 1];      // exclusive offset of the thread's first instance inside the block; [FE_BLOCK] = block total
+    __shared__ uint32_t s_pre[FE_BLOCK];          // exclusive offset of the thread's first instance inside the block
     __shared__ uint32_t s_id[FE_BLOCK];
     __shared__ uint32_t s_tile[FE_BLOCK];         // tile id of the rectangle's first tile
     __shared__ uint32_t s_w[FE_BLOCK];            // rectangle width in tiles
+    __shared__ uint32_t s_mark[FE_BLOCK];         // per wave: 64 output slots -> (lane of the splat that starts there) + 1
     __shared__ uint2 s_mask[FMT == DVS_FE_RECT_TIGHT ? FE_BLOCK : 1];
-    const uint32_t view = blockIdx.x % (uint32_t)V, blk = blockIdx.x / (uint32_t)V;
+    const uint32_t view = blockIdx.x % (uint32_t)V, blk0 = (blockIdx.x / (uint32_t)V) * 2u;
     const uint32_t nvis = seg_vis[view].count;
-    if (blk * FE_BLOCK >= nvis) return;
-    const uint32_t j = blk * FE_BLOCK + threadIdx.x;
+    if (blk0 * FE_BLOCK >= nvis) return;
     const size_t o = (size_t)view * n;
-    uint32_t id = 0, touched = 0;
-    typename FeRect<FMT>::T r = FeRect<FMT>::zero();
-    if (j < nvis) { id = sorted_ids[o + j]; r = rect_sorted[o + j]; touched = FeRect<FMT>::count(r); }
-    if constexpr (FMT == DVS_FE_RECT_TIGHT) s_mask[threadIdx.x] = make_uint2(r.z, r.w);
-    // instances before this block: the super block's offset + the block sums since
-    const uint32_t sb = blk >> 8, nprev = blk & 255u;
+    const uint32_t lane = fe_lane(), w0 = (threadIdx.x >> 6) * 64u;
+    uint32_t id[2] = {0u, 0u};
+    typename FeRect<FMT>::T r[2] = {FeRect<FMT>::zero(), FeRect<FMT>::zero()};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t j = (blk0 + (uint32_t)h) * FE_BLOCK + threadIdx.x;
+        if (j < nvis) { id[h] = sorted_ids[o + j]; r[h] = rect_sorted[o + j]; }
+    }
+    // instances before the first block: the super block's offset + the block sums since (both blocks lie in one super block: 256 is even)
+    const uint32_t sb = blk0 >> 8, nprev = blk0 & 255u;
     const uint32_t part = threadIdx.x < nprev ? block_sums[(size_t)view * nbv + (size_t)sb * 256 + threadIdx.x] : 0u;
+    const unsigned long long vbase = (unsigned long long)seg_tile[view].base + superexcl[(size_t)view * nsb + sb];
+    // (seg_tile.base is the clamped start: when it was clamped the forward has overflowed and every store below is dropped)
     uint32_t before, tot;
     (void)fe_block_excl_scan(part, tmp, &before);
-    const uint32_t pre = fe_block_excl_scan(touched, tmp, &tot);
-    s_pre[threadIdx.x] = pre;
-    s_id[threadIdx.x] = (uint32_t)o + id;
-    s_tile[threadIdx.x] = FeRect<FMT>::miny(r) * (uint32_t)tiles_x + FeRect<FMT>::minx(r);
-    s_w[threadIdx.x] = FeRect<FMT>::width(r);
-    if (threadIdx.x == 0) s_pre[FE_BLOCK] = tot;
-    __syncthreads();
-    const unsigned long long gbase = (unsigned long long)seg_tile[view].base + superexcl[(size_t)view * nsb + sb] + before;
-    // (seg_tile.base is the clamped start: when it was clamped the forward has overflowed and every store below is dropped)
-    const uint32_t lane = fe_lane(), w0 = (threadIdx.x >> 6) * 64u;
-    const uint32_t k_end = s_pre[w0 + 64u];
-    for (uint32_t k = s_pre[w0] + lane; k < k_end; k += 64u) {
-        uint32_t lo = 0;                                      // largest i in [0, 64) with s_pre[w0 + i] <= k: its range is not empty and holds k
 #pragma unroll
-        for (uint32_t step = 32u; step >= 1u; step >>= 1)
-            if (s_pre[w0 + lo + step] <= k) lo += step;
-        const uint32_t src = w0 + lo, w = s_w[src];
-        uint32_t t = k - s_pre[src];
-        if constexpr (FMT == DVS_FE_RECT_TIGHT) {             // instance t of the splat = its (t + 1)-th surviving tile
-            const uint2 m = s_mask[src];
-            if ((m.x & m.y) != 0xFFFFFFFFu) t = fe_nth_set_bit64(m.x, m.y, t);
+    for (int h = 0; h < 2; ++h) {
+        if ((blk0 + (uint32_t)h) * FE_BLOCK >= nvis) break;        // (uniform)
+        const uint32_t touched = FeRect<FMT>::count(r[h]);          // (0 for the lanes behind the visible splats: zero rectangle)
+        const uint32_t pre = fe_block_excl_scan(touched, tmp, &tot);
+        s_pre[threadIdx.x] = pre;
+        s_id[threadIdx.x] = (uint32_t)o + id[h];
+        s_tile[threadIdx.x] = FeRect<FMT>::miny(r[h]) * (uint32_t)tiles_x + FeRect<FMT>::minx(r[h]);
+        s_w[threadIdx.x] = FeRect<FMT>::width(r[h]);
+        if constexpr (FMT == DVS_FE_RECT_TIGHT) s_mask[threadIdx.x] = make_uint2(r[h].z, r[h].w);
+        // (every wave reads only what its own lanes wrote: no workgroup barrier; a wave's LDS operations execute in order)
+        const unsigned long long gbase = vbase + before;
+        const uint32_t k_beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre);
+        const uint32_t k_end = (uint32_t)__builtin_amdgcn_readlane((int)(pre + touched), 63);
+        uint32_t cur1 = 0;                                         // (lane + 1) of the splat that holds the slot before the current 64
+        for (uint32_t k0 = k_beg; k0 < k_end; k0 += 64u) {
+            s_mark[w0 + lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rel = pre - k0;                         // (wraps for splats that start before k0)
+            if (touched != 0u && rel < 64u) s_mark[w0 + rel] = lane + 1u;      // distinct slots: non-empty splats start at distinct offsets
+            __builtin_amdgcn_wave_barrier();
+            uint32_t m = s_mark[w0 + lane];
+            __builtin_amdgcn_wave_barrier();
+            m = fe_wave_incl_max(m);
+            m = m > cur1 ? m : cur1;                               // slots in front of the first start belong to the carried splat
+            cur1 = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+            const uint32_t k = k0 + lane;
+            if (k < k_end) {
+                const uint32_t src = w0 + m - 1u, w = s_w[src];
+                uint32_t t = k - s_pre[src];
+                if constexpr (FMT == DVS_FE_RECT_TIGHT) {         // instance t of the splat = its (t + 1)-th surviving tile
+                    const uint2 mk = s_mask[src];
+                    if ((mk.x & mk.y) != 0xFFFFFFFFu) t = fe_nth_set_bit64(mk.x, mk.y, t);
+                }
+                // row = t / w by a float quotient and one correction step (t < 2^24: a rectangle has fewer tiles than the screen)
+                uint32_t q = (uint32_t)((float)t * __builtin_amdgcn_rcpf((float)w));
+                int32_t rem = (int32_t)(t - q * w);
+                if (rem < 0) { --q; rem += (int32_t)w; } else if (rem >= (int32_t)w) { ++q; rem -= (int32_t)w; }
+                const unsigned long long g = gbase + k;
+                if (g < capacity) {
+                    const uint32_t tile = s_tile[src] + q * (uint32_t)tiles_x + (uint32_t)rem;
+                    if (key16) reinterpret_cast<uint16_t*>(inst_tile)[g] = (uint16_t)tile; else inst_tile[g] = tile;
+                    inst_splat[g] = s_id[src];
+                }
+            }
         }
-        // row = t / w by a float quotient and one correction step (t < 2^24: a rectangle has fewer tiles than the screen)
-        uint32_t q = (uint32_t)((float)t * __builtin_amdgcn_rcpf((float)w));
-        int32_t rem = (int32_t)(t - q * w);
-        if (rem < 0) { --q; rem += (int32_t)w; } else if (rem >= (int32_t)w) { ++q; rem -= (int32_t)w; }
-        const unsigned long long g = gbase + k;
-        if (g < capacity) {
-            const uint32_t tile = s_tile[src] + q * (uint32_t)tiles_x + (uint32_t)rem;
-            if (key16) reinterpret_cast<uint16_t*>(inst_tile)[g] = (uint16_t)tile; else inst_tile[g] = tile;
-            inst_splat[g] = s_id[src];
-        }
+        before += tot;
+        __builtin_amdgcn_wave_barrier();                           // (the next block's LDS writes stay behind this block's reads)
     }
 }
 
@@ -678,7 +712,7 @@ hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, co
                                   int tiles_x, uint32_t* inst_tile, uint32_t* inst_splat, int key16) {
     if (n <= 0 || V <= 0) return hipSuccess;
     const uint32_t nbv = (uint32_t)((n + FE_BLOCK - 1) / FE_BLOCK), nsb = (nbv + 255u) / 256u;
-    const dim3 grid(nbv * (uint32_t)V), grid3(((nbv + 3u) / 4u) * (uint32_t)V), blk(FE_BLOCK);
+    const dim3 grid(((nbv + 1u) / 2u) * (uint32_t)V), grid3(((nbv + 3u) / 4u) * (uint32_t)V), blk(FE_BLOCK);
     if (stage == 0) {
 #define FE_A3(F) hipLaunchKernelGGL(k_seg_blocksum<F>, grid3, blk, 0, st, n, V, nbv, nsb, seg_vis, sorted_ids, (const FeRect<F>::T*)rect, (FeRect<F>::T*)rect_sorted, block_sums, super)
         if (rect_fmt == DVS_FE_RECT_U8) FE_A3(DVS_FE_RECT_U8); else if (rect_fmt == DVS_FE_RECT_U16) FE_A3(DVS_FE_RECT_U16); else FE_A3(DVS_FE_RECT_TIGHT);
