@@ -461,6 +461,26 @@ __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float p
 }
 
 // ---- A9 ---------------------------------------------------------------------------------------
+// dL/d(unit direction) of a view's colour: gdir[d] = sum_k d(basis_k)/d(dir_d) * s_k with s_k = sum_ch shN[k][ch] * gc[ch] (the colour
+// gradient folded into the coefficients FIRST: 45 + 33 fused multiply-adds per (view, splat) instead of the 45 x 3 x 3 multiply-multiply-add
+// triples of rounds 1-5a — k_preprocess_bwd_views is 60 % vector-ALU-busy by the counters, profiles/r05b_pmc_sq.txt). Only the structurally
+// non-zero derivative entries are read (dvs_sh_basis_grad, dvs_device.h:211). Both A9 kernels use this one form, so a batch stays
+// bit-identical to its views run one by one.
+__device__ __forceinline__ void a9_dir_grad(int deg, float x, float y, float z, const float s[16], float g[3]) {
+    float db[16][3];
+    dvs_sh_basis_grad(deg, x, y, z, db);
+#define A9_T(k, d) g[d] = __builtin_fmaf(db[k][d], s[k], g[d])
+    if (deg >= 1) { A9_T(1, 1); A9_T(2, 2); A9_T(3, 0); }
+    if (deg >= 2) {
+        A9_T(4, 0); A9_T(4, 1); A9_T(5, 1); A9_T(5, 2); A9_T(6, 0); A9_T(6, 1); A9_T(6, 2); A9_T(7, 0); A9_T(7, 2); A9_T(8, 0); A9_T(8, 1);
+    }
+    if (deg >= 3) {
+        A9_T(9, 0); A9_T(9, 1); A9_T(10, 0); A9_T(10, 1); A9_T(10, 2); A9_T(11, 0); A9_T(11, 1); A9_T(11, 2); A9_T(12, 0); A9_T(12, 1); A9_T(12, 2);
+        A9_T(13, 0); A9_T(13, 1); A9_T(13, 2); A9_T(14, 0); A9_T(14, 1); A9_T(14, 2); A9_T(15, 0); A9_T(15, 1);
+    }
+#undef A9_T
+}
+
 template <bool ACCUM, bool TILED>
 __global__ void __launch_bounds__(PP_BLOCK)
 k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
@@ -514,11 +534,13 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
         const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
         const float inv_dl = 1.0f / dl;
         const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
-        float bas[16], dbas[16][3];
+        float bas[16];
         dvs_sh_basis(deg, ux, uy, uz, bas);
-        dvs_sh_basis_grad(deg, ux, uy, uz, dbas);
         const int ncoef = (deg + 1) * (deg + 1);
         float gdir[3] = {0.f, 0.f, 0.f};
+        float sk[16];                                        // s_k = sum_ch shN[k][ch] * gc[ch] (a9_dir_grad)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sk[k] = 0.f;
         float gc[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -541,7 +563,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
                         if (e < 45 && e / 3 + 1 < ncoef) {
                             const int k = e / 3 + 1, ch = e % 3;
                             gv[u] = bas[k] * gc[ch];
-                            gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                            sk[k] = __builtin_fmaf(qv[u], gc[ch], sk[k]);
                         }
                     }
                 }
@@ -552,17 +574,21 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
                 }
             }
         } else {
-            for (int k = 1; k < ncoef; ++k) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float coef = row[(k - 1) * 3 + ch];
-                    row[(k - 1) * 3 + ch] = bas[k] * gc[ch];       // overwrite the staged parameter with its gradient
-                    gdir[0] += dbas[k][0] * coef * gc[ch]; gdir[1] += dbas[k][1] * coef * gc[ch]; gdir[2] += dbas[k][2] * coef * gc[ch];
+            for (int k = 1; k < 16; ++k) {
+                if (k < ncoef) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float coef = row[(k - 1) * 3 + ch];
+                        row[(k - 1) * 3 + ch] = bas[k] * gc[ch];   // overwrite the staged parameter with its gradient
+                        sk[k] = __builtin_fmaf(coef, gc[ch], sk[k]);
+                    }
                 }
             }
             for (int e = (ncoef - 1) * 3; e < 45; ++e) row[e] = 0.f;
         }
         {
+            a9_dir_grad(deg, ux, uy, uz, sk, gdir);
             const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
             gp[0] += (gdir[0] - ux * ug) * inv_dl; gp[1] += (gdir[1] - uy * ug) * inv_dl; gp[2] += (gdir[2] - uz * ug) * inv_dl;
         }
@@ -683,15 +709,16 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
             const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
             const float inv_dl = 1.0f / dl;
             const float ux = dxw * inv_dl, uy = dyw * inv_dl, uz = dzw * inv_dl;
-            float dbas[16][3];
-            dvs_sh_basis_grad(deg, ux, uy, uz, dbas);
             float gdir[3] = {0.f, 0.f, 0.f};
+            float sk[16];                                    // s_k = sum_ch shN[k][ch] * gc[ch] (a9_dir_grad)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sk[k] = 0.f;
             float gc[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch]; gcol[ch] = gc[ch]; }
             // The coefficients come from the tiled array again for every view (after the first view they are L2 hits; keeping 48 of
             // them in registers across the loop would cost more registers than there are). They are requested in three groups of
-            // four 16-B chunks, unconditionally: basis derivatives above `deg` are zero, so unused bands drop out by themselves — a
+            // four 16-B chunks, unconditionally: a9_dir_grad does not read the sums of the bands above `deg` — a
             // test per chunk made every chunk its own dependent L2 round trip (12 per view in a latency-bound kernel).
             if (deg > 0) {
 #pragma unroll
@@ -707,7 +734,7 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
                             const int e = (g4 * 4 + c) * 4 + u;              // compile-time: coefficient k = e/3 + 1, channel e%3
                             if (e < 45) {
                                 const int k = e / 3 + 1, ch = e % 3;
-                                gdir[0] += dbas[k][0] * qv[u] * gc[ch]; gdir[1] += dbas[k][1] * qv[u] * gc[ch]; gdir[2] += dbas[k][2] * qv[u] * gc[ch];
+                                sk[k] = __builtin_fmaf(qv[u], gc[ch], sk[k]);
                             }
                         }
                     }
@@ -716,6 +743,7 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
             float gpv[3] = {0.f, 0.f, 0.f}, gscv[3], gqv[4], g_opv;
             float2 dmv;
             {
+                a9_dir_grad(deg, ux, uy, uz, sk, gdir);
                 const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
                 gpv[0] += (gdir[0] - ux * ug) * inv_dl; gpv[1] += (gdir[1] - uy * ug) * inv_dl; gpv[2] += (gdir[2] - uz * ug) * inv_dl;
             }
