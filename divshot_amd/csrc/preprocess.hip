@@ -110,140 +110,136 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     const DvsCam cam = dvs_load_cam(view);
     const int64_t o = (int64_t)view * n + i;
 
-    int out_radius = 0;
-    uint32_t out_tiles = 0, out_flags = 0, out_key = 0xFFFFFFFFu;
-    uint2 out_rect = make_uint2(0u, 0u);
-    unsigned long long out_mask = 0ull;
-    float2 out_mean = make_float2(0.f, 0.f);
-    float out_depth = 0.f;
-    float4 out_co = make_float4(0.f, 0.f, 0.f, 0.f);
-    float out_rgb[3] = {0.f, 0.f, 0.f};
+    // Straight-line and predicated: every cull test only clears `ok`, and the outputs are selected once at the end. (Rounds 1-5b left the
+    // body through seven early exits; each exit level re-materialised the seventeen zero defaults of the outputs and kept a saved EXEC mask
+    // alive — 190 v_mov and 78 SGPR-spill v_readlane per view in a kernel that is 80 % vector-ALU-busy, profiles/r05b_pmc_sq.txt — while a
+    // wave practically never has all 64 splats culled, so the exits saved nothing.) Same expressions in the same order for the lanes that
+    // survive: bit-identical outputs; culled lanes compute on whatever they hold (NaN / inf are harmless, nothing is stored from them).
+    const float px = in_px, py = in_py, pz = in_pz;
+    const float tx = dvs_xform(cam.view, px, py, pz, 0);
+    const float ty = dvs_xform(cam.view, px, py, pz, 1);
+    const float tz = dvs_xform(cam.view, px, py, pz, 2);
+    // a NaN log-scale or opacity logit culls the splat (the clamps inside dvs_exp_det would otherwise turn it into a number)
+    bool ok = (tz > DVS_NEAR) && (in_s0 == in_s0) && (in_s1 == in_s1) && (in_s2 == in_s2) && (in_op == in_op);
+    const float hx = dvs_xform(cam.proj, px, py, pz, 0);
+    const float hy = dvs_xform(cam.proj, px, py, pz, 1);
+    const float hw = dvs_xform(cam.proj, px, py, pz, 3);
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float ndc_x = hx * pw, ndc_y = hy * pw;
 
-    do {
-        const float px = in_px, py = in_py, pz = in_pz;
-        const float tx = dvs_xform(cam.view, px, py, pz, 0);
-        const float ty = dvs_xform(cam.view, px, py, pz, 1);
-        const float tz = dvs_xform(cam.view, px, py, pz, 2);
-        if (!(tz > DVS_NEAR)) break;
-        // a NaN log-scale or opacity logit culls the splat (the clamps inside dvs_exp_det would otherwise turn it into a number)
-        if (!(in_s0 == in_s0) || !(in_s1 == in_s1) || !(in_s2 == in_s2) || !(in_op == in_op)) break;
-        const float hx = dvs_xform(cam.proj, px, py, pz, 0);
-        const float hy = dvs_xform(cam.proj, px, py, pz, 1);
-        const float hw = dvs_xform(cam.proj, px, py, pz, 3);
-        const float pw = 1.0f / (hw + 0.0000001f);
-        const float ndc_x = hx * pw, ndc_y = hy * pw;
+    const float s[3] = {dvs_exp_det(in_s0), dvs_exp_det(in_s1), dvs_exp_det(in_s2)};
+    const float4 q4 = in_q;
+    const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
+    const float qn = dvs_sqrt_rn(((qr * qr + qx * qx) + qy * qy) + qz * qz);
+    ok = ok && (qn > 0.f);
+    const float inv_qn = 1.0f / qn;
+    float R[9];
+    dvs_quat_to_rot(qr * inv_qn, qx * inv_qn, qy * inv_qn, qz * inv_qn, R);
+    float c3[6];
+    dvs_cov3d(s, R, c3);
 
-        const float s[3] = {dvs_exp_det(in_s0), dvs_exp_det(in_s1), dvs_exp_det(in_s2)};
-        const float4 q4 = in_q;
-        const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
-        const float qn = dvs_sqrt_rn(((qr * qr + qx * qx) + qy * qy) + qz * qz);
-        if (!(qn > 0.f)) break;
-        const float inv_qn = 1.0f / qn;
-        float R[9];
-        dvs_quat_to_rot(qr * inv_qn, qx * inv_qn, qy * inv_qn, qz * inv_qn, R);
-        float c3[6];
-        dvs_cov3d(s, R, c3);
-
-        const float limx = DVS_FOV_GUARD * cam.tan_fovx, limy = DVS_FOV_GUARD * cam.tan_fovy;
-        const float txtz = tx / tz, tytz = ty / tz;
-        uint32_t fl = 0;
-        if (txtz < -limx || txtz > limx) fl |= DVS_FLAG_CLAMP_X;
-        if (tytz < -limy || tytz > limy) fl |= DVS_FLAG_CLAMP_Y;
-        const float txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
-        const float tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
-        const float fx = cam.focal_x, fy = cam.focal_y;
-        const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz);
-        const float J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
-        float T0[3], T1[3];
+    const float limx = DVS_FOV_GUARD * cam.tan_fovx, limy = DVS_FOV_GUARD * cam.tan_fovy;
+    const float txtz = tx / tz, tytz = ty / tz;
+    uint32_t fl = 0;
+    if (txtz < -limx || txtz > limx) fl |= DVS_FLAG_CLAMP_X;
+    if (tytz < -limy || tytz > limy) fl |= DVS_FLAG_CLAMP_Y;
+    const float txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    const float tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const float fx = cam.focal_x, fy = cam.focal_y;
+    const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz);
+    const float J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
+    float T0[3], T1[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            T0[k] = J00 * cam.view[k * 4 + 0] + J02 * cam.view[k * 4 + 2];
-            T1[k] = J11 * cam.view[k * 4 + 1] + J12 * cam.view[k * 4 + 2];
-        }
-        const float v0x = (c3[0] * T0[0] + c3[1] * T0[1]) + c3[2] * T0[2];
-        const float v0y = (c3[1] * T0[0] + c3[3] * T0[1]) + c3[4] * T0[2];
-        const float v0z = (c3[2] * T0[0] + c3[4] * T0[1]) + c3[5] * T0[2];
-        const float v1x = (c3[0] * T1[0] + c3[1] * T1[1]) + c3[2] * T1[2];
-        const float v1y = (c3[1] * T1[0] + c3[3] * T1[1]) + c3[4] * T1[2];
-        const float v1z = (c3[2] * T1[0] + c3[4] * T1[1]) + c3[5] * T1[2];
-        const float cxx = (T0[0] * v0x + T0[1] * v0y) + T0[2] * v0z;
-        const float cxy = (T0[0] * v1x + T0[1] * v1y) + T0[2] * v1z;
-        const float cyy = (T1[0] * v1x + T1[1] * v1y) + T1[2] * v1z;
+    for (int k = 0; k < 3; ++k) {
+        T0[k] = J00 * cam.view[k * 4 + 0] + J02 * cam.view[k * 4 + 2];
+        T1[k] = J11 * cam.view[k * 4 + 1] + J12 * cam.view[k * 4 + 2];
+    }
+    const float v0x = (c3[0] * T0[0] + c3[1] * T0[1]) + c3[2] * T0[2];
+    const float v0y = (c3[1] * T0[0] + c3[3] * T0[1]) + c3[4] * T0[2];
+    const float v0z = (c3[2] * T0[0] + c3[4] * T0[1]) + c3[5] * T0[2];
+    const float v1x = (c3[0] * T1[0] + c3[1] * T1[1]) + c3[2] * T1[2];
+    const float v1y = (c3[1] * T1[0] + c3[3] * T1[1]) + c3[4] * T1[2];
+    const float v1z = (c3[2] * T1[0] + c3[4] * T1[1]) + c3[5] * T1[2];
+    const float cxx = (T0[0] * v0x + T0[1] * v0y) + T0[2] * v0z;
+    const float cxy = (T0[0] * v1x + T0[1] * v1y) + T0[2] * v1z;
+    const float cyy = (T1[0] * v1x + T1[1] * v1y) + T1[2] * v1z;
 
-        const float a = cxx + DVS_LOWPASS, b = cxy, c = cyy + DVS_LOWPASS;
-        const float det = a * c - b * b;
-        if (!(det > 0.f)) break;
-        float opac = dvs_sigmoid_det(in_op);
-        if (antialias) {
-            const float det_orig = cxx * cyy - b * b;
-            const float aa = dvs_sqrt_rn(fmaxf(0.f, det_orig / det));
-            opac = opac * aa;
-        }
-        if (!(opac > DVS_ALPHA_MIN)) break;
-        const float det_inv = 1.0f / det;
-        const float mid = 0.5f * (a + c);
-        const float lam = mid + dvs_sqrt_rn(fmaxf(0.1f, mid * mid - det));
-        const float radf = ceilf(3.0f * dvs_sqrt_rn(lam));
-        const float m2x = ((ndc_x + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
-        const float m2y = ((ndc_y + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
-        const float gx = (float)tiles_x, gy = (float)tiles_y, inv_tile = 1.0f / DVS_TILE;
-        const int rminx = (int)fminf(gx, fmaxf(0.f, (m2x - radf) * inv_tile));
-        const int rminy = (int)fminf(gy, fmaxf(0.f, (m2y - radf) * inv_tile));
-        const int rmaxx = (int)fminf(gx, fmaxf(0.f, (m2x + radf + (float)(DVS_TILE - 1)) * inv_tile));
-        const int rmaxy = (int)fminf(gy, fmaxf(0.f, (m2y + radf + (float)(DVS_TILE - 1)) * inv_tile));
-        const int touched = (rmaxx - rminx) * (rmaxy - rminy);
-        if (touched <= 0) break;
+    const float a = cxx + DVS_LOWPASS, b = cxy, c = cyy + DVS_LOWPASS;
+    const float det = a * c - b * b;
+    ok = ok && (det > 0.f);
+    float opac = dvs_sigmoid_det(in_op);
+    if (antialias) {
+        const float det_orig = cxx * cyy - b * b;
+        const float aa = dvs_sqrt_rn(fmaxf(0.f, det_orig / det));
+        opac = opac * aa;
+    }
+    ok = ok && (opac > DVS_ALPHA_MIN);
+    const float det_inv = 1.0f / det;
+    const float mid = 0.5f * (a + c);
+    const float lam = mid + dvs_sqrt_rn(fmaxf(0.1f, mid * mid - det));
+    const float radf = ceilf(3.0f * dvs_sqrt_rn(lam));
+    const float m2x = ((ndc_x + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
+    const float m2y = ((ndc_y + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
+    const float gx = (float)tiles_x, gy = (float)tiles_y, inv_tile = 1.0f / DVS_TILE;
+    const int rminx = (int)fminf(gx, fmaxf(0.f, (m2x - radf) * inv_tile));
+    const int rminy = (int)fminf(gy, fmaxf(0.f, (m2y - radf) * inv_tile));
+    const int rmaxx = (int)fminf(gx, fmaxf(0.f, (m2x + radf + (float)(DVS_TILE - 1)) * inv_tile));
+    const int rmaxy = (int)fminf(gy, fmaxf(0.f, (m2y + radf + (float)(DVS_TILE - 1)) * inv_tile));
+    const int touched = (rmaxx - rminx) * (rmaxy - rminy);
+    ok = ok && (touched > 0);
 
-        const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
-        const float dl = dvs_sqrt_rn((dx * dx + dy * dy) + dz * dz);
-        const float inv_dl = 1.0f / dl;
-        float bas[16];
-        dvs_sh_basis(deg, dx * inv_dl, dy * inv_dl, dz * inv_dl, bas);
-        const int ncoef = (deg + 1) * (deg + 1);
-        const float in_dc[3] = {in_dc0, in_dc1, in_dc2};
-        float colr[3] = {bas[0] * in_dc[0], bas[0] * in_dc[1], bas[0] * in_dc[2]};
-        if (TILED) {
-            const int nchunk = ((ncoef - 1) * 3 + 3) >> 2;
+    const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+    const float dl = dvs_sqrt_rn((dx * dx + dy * dy) + dz * dz);
+    const float inv_dl = 1.0f / dl;
+    float bas[16];
+    dvs_sh_basis(deg, dx * inv_dl, dy * inv_dl, dz * inv_dl, bas);
+    const int ncoef = (deg + 1) * (deg + 1);
+    const float in_dc[3] = {in_dc0, in_dc1, in_dc2};
+    float colr[3] = {bas[0] * in_dc[0], bas[0] * in_dc[1], bas[0] * in_dc[2]};
+    if (TILED) {
+        const int nchunk = ((ncoef - 1) * 3 + 3) >> 2;
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                if (c < nchunk) {
-                    const float4 q = in_q4[c];
-                    const float qv[4] = {q.x, q.y, q.z, q.w};
+        for (int c = 0; c < 12; ++c) {
+            if (c < nchunk) {
+                const float4 q = in_q4[c];
+                const float qv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = c * 4 + u;                     // compile-time: coefficient e/3 + 1, channel e%3
-                        if (e < 45 && e / 3 + 1 < ncoef) colr[e % 3] = colr[e % 3] + bas[e / 3 + 1] * qv[u];
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int e = c * 4 + u;                     // compile-time: coefficient e/3 + 1, channel e%3
+                    if (e < 45 && e / 3 + 1 < ncoef) colr[e % 3] = colr[e % 3] + bas[e / 3 + 1] * qv[u];
                 }
             }
-        } else {
-            const float* row = lds + threadIdx.x * 45;
-            for (int k = 1; k < ncoef; ++k)
+        }
+    } else {
+        const float* row = lds + threadIdx.x * 45;
+        for (int k = 1; k < ncoef; ++k)
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) colr[ch] = colr[ch] + bas[k] * row[(k - 1) * 3 + ch];
-        }
+            for (int ch = 0; ch < 3; ++ch) colr[ch] = colr[ch] + bas[k] * row[(k - 1) * 3 + ch];
+    }
+    float rgb_c[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float col = colr[ch] + 0.5f;
-            if (col < 0.f) { fl |= (1u << ch); col = 0.f; }
-            out_rgb[ch] = col;
+    for (int ch = 0; ch < 3; ++ch) {
+        float col = colr[ch] + 0.5f;
+        if (col < 0.f) { fl |= (1u << ch); col = 0.f; }
+        rgb_c[ch] = col;
+    }
+    const int out_radius = ok ? (int)fminf(radf, (float)(1 << 30)) : 0;
+    const float2 out_mean = ok ? make_float2(m2x, m2y) : make_float2(0.f, 0.f);
+    const float out_depth = ok ? tz : 0.f;
+    const uint32_t out_key = ok ? __float_as_uint(tz) : 0xFFFFFFFFu;
+    const float4 out_co = ok ? make_float4(c * det_inv, -b * det_inv, a * det_inv, opac) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float out_rgb[3] = {ok ? rgb_c[0] : 0.f, ok ? rgb_c[1] : 0.f, ok ? rgb_c[2] : 0.f};
+    const uint32_t out_flags = ok ? fl : 0u;
+    uint32_t out_tiles = ok ? (uint32_t)touched : 0u;
+    const uint2 out_rect = ok ? make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16)) : make_uint2(0u, 0u);
+    unsigned long long out_mask = 0ull;
+    if (rect16 && ok) {    // DVS_TILES_TIGHT: only the tiles the alpha >= 1/255 ellipse reaches (rectangles of more than 64 tiles stay whole)
+        out_mask = ~0ull;
+        if (touched <= 64) {
+            out_mask = dvs_tight_tile_mask(out_co.x, out_co.y, out_co.z, opac, m2x, m2y, rminx, rminy, rmaxx, rmaxy);
+            out_tiles = (uint32_t)__popcll(out_mask);
         }
-        out_radius = (int)fminf(radf, (float)(1 << 30));
-        out_mean = make_float2(m2x, m2y);
-        out_depth = tz;
-        out_key = __float_as_uint(tz);
-        out_co = make_float4(c * det_inv, -b * det_inv, a * det_inv, opac);
-        out_flags = fl;
-        out_tiles = (uint32_t)touched;
-        out_rect = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
-        if (rect16) {          // DVS_TILES_TIGHT: only the tiles the alpha >= 1/255 ellipse reaches (rectangles of more than 64 tiles stay whole)
-            out_mask = ~0ull;
-            if (touched <= 64) {
-                out_mask = dvs_tight_tile_mask(out_co.x, out_co.y, out_co.z, opac, m2x, m2y, rminx, rminy, rmaxx, rmaxy);
-                out_tiles = (uint32_t)__popcll(out_mask);
-            }
-        }
-    } while (0);
+    }
 
     radii[o] = out_radius;
     depth[o] = out_depth;
@@ -678,7 +674,6 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
     const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
     const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
     const float in_op = opacity[il];
-    const int ncoef = (deg + 1) * (deg + 1);
     const float4* p4 = reinterpret_cast<const float4*>(shN);
     float gp[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
     float g_op = 0.f;
