@@ -34,14 +34,19 @@
 
 __device__ __forceinline__ uint32_t fe_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// peers = lanes of this wave holding the same b-bit digit (invalid lanes never match valid ones)
+// peers = lanes of this wave holding the same b-bit digit (invalid lanes never match valid ones). Per bit: the lane's bit as a 0 / ~0 word
+// (v_bfe_i32), its ballot, and ONE v_bitop3_b32 per mask half — peers & ~(ballot ^ word) keeps the lanes whose bit equals this lane's —
+// four vector instructions (the select-based form of rounds 2-5b took eight; the scatters are ~65 % vector-ALU-busy).
 __device__ __forceinline__ uint64_t fe_match(uint32_t d, bool valid, uint32_t b) {
-    uint64_t peers = __ballot(valid);
+    const uint64_t v0 = __ballot(valid);
+    uint32_t lo = (uint32_t)v0, hi = (uint32_t)(v0 >> 32);
     for (uint32_t k = 0; k < b; ++k) {
-        const bool bit = (d >> k) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
+        const uint32_t m = (uint32_t)(((int32_t)(d << (31u - k))) >> 31);
+        const uint64_t bal = __ballot(m != 0u);
+        lo = lo & ~((uint32_t)bal ^ m);
+        hi = hi & ~((uint32_t)(bal >> 32) ^ m);
     }
+    const uint64_t peers = ((uint64_t)hi << 32) | lo;
     return valid ? peers : 0ull;
 }
 
