@@ -831,12 +831,13 @@ k_sh_grad_combine(CombineViews views_arg /* MUST stay the first parameter: read 
                 const float inv_dl = 1.0f / dl;
                 float bas[16];
                 dvs_sh_basis(deg, dxw * inv_dl, dyw * inv_dl, dzw * inv_dl, bas);
+                // (explicit FMAs: this file is compiled without contraction for A2's sake, and the kernel is 60 % vector-ALU-busy)
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) acc0[ch] += bas[0] * gc[ch];
+                for (int ch = 0; ch < 3; ++ch) acc0[ch] = __builtin_fmaf(bas[0], gc[ch], acc0[ch]);
 #pragma unroll
                 for (int k = 1; k < 16; ++k)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) acc[(k - 1) * 3 + ch] += bas[k] * gc[ch];
+                    for (int ch = 0; ch < 3; ++ch) acc[(k - 1) * 3 + ch] = __builtin_fmaf(bas[k], gc[ch], acc[(k - 1) * 3 + ch]);
             }
             float4* d4 = reinterpret_cast<float4*>(g_shN);
 #pragma unroll
