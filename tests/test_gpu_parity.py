@@ -104,6 +104,20 @@ def test_pipeline_parity(rast, oracle_mod, name):
     check_pipeline_parity(rast, oracle_mod, name, CONFIGS[name])
 
 
+def test_wide_image_takes_the_16_bit_rectangles(gpu_device, oracle_mod):
+    """A tile grid of more than 255 columns (here 4208 x 48 pixels = 263 x 3 tiles) cannot pack a splat's tile rectangle into four
+    bytes: A2 writes the 4 x u16 form and A3 / A4 run their DVS_FE_RECT_U16 instantiations (frontend.hip). Every stage against the oracle
+    at the usual bars — bins bit-exact."""
+    from divshot_amd.raster import Rasterizer
+    r = Rasterizer(0, max_splats=8192, max_w=4208, max_h=48)
+    r.keep_intermediates(True)
+    try:
+        check_pipeline_parity(r, oracle_mod, "wide_4k_4208x48_deg1", (4000, 4208, 48, 1, 41, 0.3, False, (0.1, 0.2, 0.3)))
+        assert r.num_rendered > 4000
+    finally:
+        r.close()
+
+
 def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, cam_index=0):
     """Every stage of one view against the oracle (also used at full size by tests/test_gpu_large.py)."""
     n, W, H, deg, seed, soff, aa, bg = cfg
