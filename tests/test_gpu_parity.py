@@ -106,14 +106,39 @@ def test_pipeline_parity(rast, oracle_mod, name):
 
 def test_wide_image_takes_the_16_bit_rectangles(gpu_device, oracle_mod):
     """A tile grid of more than 255 columns (here 4208 x 48 pixels = 263 x 3 tiles) cannot pack a splat's tile rectangle into four
-    bytes: A2 writes the 4 x u16 form and A3 / A4 run their DVS_FE_RECT_U16 instantiations (frontend.hip). Every stage against the oracle
-    at the usual bars — bins bit-exact."""
-    from divshot_amd.raster import Rasterizer
-    r = Rasterizer(0, max_splats=8192, max_w=4208, max_h=48)
-    r.keep_intermediates(True)
+    bytes: A2 writes the 4 x u16 form and A3 / A4 run their DVS_FE_RECT_U16 instantiations (frontend.hip). Bins bit-exact against the
+    oracle, preprocess floats bit-identical, image within 1e-4 outside the fragile pixels, gradients within 1e-3 relative L2 per group of
+    the fp32 oracle (at this shape — a focal length of 3644 pixels — the oracle's own fp32-vs-fp64 replay agreement is 1.3e-4 on the
+    positions, just over the 1e-4 test_pipeline_parity asks of it, so that test's decision-replay bars are not applied here)."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H, deg, seed, soff, bg = 4000, 4208, 48, 1, 41, 0.3, (0.1, 0.2, 0.3)
+    spec, P, cam, tgt = scene(n, W, H, deg, seed, scale_offset=soff, bg=bg)
+    r = Rasterizer(0, max_splats=8192, max_w=W, max_h=H)
     try:
-        check_pipeline_parity(r, oracle_mod, "wide_4k_4208x48_deg1", (4000, 4208, 48, 1, 41, 0.3, False, (0.1, 0.2, 0.3)))
-        assert r.num_rendered > 4000
+        Pd = params_to_device(P, r.tdev)
+        img = r.forward(Pd, cam, sh_degree=deg, absgrad=True)
+        torch.cuda.synchronize()
+        saved, keys = r.saved(), r.sorted_keys()
+        o = oracle_mod.Oracle(np.float32)
+        ref_img = o.forward(P, cam, sh_degree=deg)
+        for k in ("radii", "tiles_touched", "flags"):
+            np.testing.assert_array_equal(saved[k], o.get(k))
+        for k in ("mean2d", "depth", "conic_opacity", "rgb"):
+            assert np.array_equal(saved[k].view(np.uint32), o.get(k).reshape(saved[k].shape).view(np.uint32)), k
+        np.testing.assert_array_equal(keys, o.get("keys"))
+        np.testing.assert_array_equal(saved["vals"], o.get("vals"))
+        np.testing.assert_array_equal(saved["ranges"], o.get("ranges"))
+        assert r.num_rendered == o.get("vals").size > n and int((keys >> 32).max()) % 263 > 255
+        ok = ~o.get("fragile").astype(bool)
+        assert np.abs(img.cpu().numpy() - ref_img)[:, ok].max() < 1e-4
+        dL = ((img.cpu().numpy() - tgt) / tgt[0].size).astype(np.float32)
+        g = r.backward(torch.from_numpy(dL).to(r.tdev))
+        torch.cuda.synchronize()
+        ref = o.backward(dL)
+        for k in KEYS:
+            a, b = g[k].cpu().numpy().astype(np.float64).ravel(), ref[k].astype(np.float64).ravel()
+            assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(b), 1e-30), k
     finally:
         r.close()
 
@@ -954,6 +979,55 @@ def test_depth_sort_digit_width_follows_the_key_range(gpu_device, oracle_mod, zm
     ok = ~o.get("fragile").astype(bool)
     assert np.abs(img.cpu().numpy() - ref)[:, ok].max() < 1e-4
     r.close()
+
+
+@pytest.mark.parametrize("asy", [False, True])
+def test_multi_view_batch_with_a_view_that_sees_nothing(gpu_device, asy):
+    """A batch in which one camera looks the other way: its segment of both sorts is EMPTY (zero visible splats, zero instances — every
+    per-view descriptor of the segmented front end has count 0). The other views must come out exactly as alone, the blind view is its
+    background, and the gradients are those of the two seeing views. Synchronous and asynchronous forwards."""
+    import copy, torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H = 3001, 176, 112
+    spec = dv.make_spec(n, W, H, sh_degree=2, n_cams=3, seed=77)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, 0), dv.synth_camera(spec, 1), dv.synth_camera(spec, 2)]
+    blind = cams[1]
+    for c in range(4):
+        blind.view[c * 4 + 2] = -blind.view[c * 4 + 2]          # depth axis flipped: everything is behind this camera
+    blind.bg[0], blind.bg[1], blind.bg[2] = 0.25, 0.5, 0.75
+    tg = [torch.from_numpy(dv.synth_target(spec, i)).cuda() for i in range(3)]
+    single = Rasterizer(0, max_splats=n, max_w=W, max_h=H)
+    batch = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=3)
+    batch.set_async(asy)
+    Pd = params_to_device(P, single.tdev)
+    ref_imgs, ref_saved, ref = [], [], None
+    for v in range(3):
+        img = single.forward(Pd, cams[v], sh_degree=2, absgrad=True)
+        ref_imgs.append(img.clone()); ref_saved.append(single.saved())
+        dL = ((img - tg[v]) / (W * H)).contiguous()
+        ref = single.backward(dL, grads=ref, accumulate=ref is not None)
+        if v == 0:
+            ref = {k: t.clone() for k, t in ref.items()}
+    assert ref_saved[1]["vals"].size == 0 and (ref_saved[1]["radii"] == 0).all()
+    for rep in range(2):                                          # twice: the second forward starts from the first one's arenas and counters
+        imgs = batch.forward_views(Pd, cams, sh_degree=2, absgrad=True)
+        torch.cuda.synchronize()
+        assert batch.get_num_rendered() == ref_saved[0]["vals"].size + ref_saved[2]["vals"].size
+        for v in range(3):
+            assert torch.equal(imgs[v], ref_imgs[v]), f"image of view {v}"
+            sv = batch.view_saved(v)
+            for k in ("radii", "flags", "tiles_touched", "vals", "sorted_tile", "ranges", "n_contrib"):
+                np.testing.assert_array_equal(sv[k], ref_saved[v][k], err_msg=f"view {v} {k}")
+        bgc = torch.tensor([0.25, 0.5, 0.75], device=imgs.device).view(3, 1, 1)
+        assert torch.equal(imgs[1], bgc.expand(3, H, W))
+        dL_all = torch.stack([(imgs[v] - tg[v]) / (W * H) for v in range(3)]).contiguous()
+        g = batch.backward_views(dL_all)
+        torch.cuda.synchronize()
+        for k in KEYS:
+            m, worst = rel_close(g[k].cpu().numpy(), ref[k].cpu().numpy(), 1e-4, 2e-6)
+            assert m.all(), (rep, k, worst)
+    single.close(); batch.close()
 
 
 def test_tile_ranges_fused_into_the_sort_equal_the_separate_kernel(gpu_device):
