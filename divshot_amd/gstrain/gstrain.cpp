@@ -253,7 +253,7 @@ void GaussianTrainerScene::Impl::report_config() const {
           cfg.densifyStrategy, strat[std::min(2, std::max(0, cfg.densifyStrategy))], cfg.pruneStrategy,
           cfg.pruneStrategy > 0 ? "light prune: opacity < pruneOpacity or scale > pruneScale3d" : "off", cfg.pruneInterval, cfg.refineStopIter,
           cfg.capMax, cfg.packLevel, (cfg.packLevel & PackF32ToU8) ? "PackF32ToU8: 8-bit training views" : "fp32 training views",
-          (cfg.packLevel & PackTileID) ? ", PackTileID: always on here (tile ids are sorted as 8-bit digits of a 32-bit key)" : "",
+          (cfg.packLevel & PackTileID) ? ", PackTileID: always on here (the tile sort's keys are tile ids inside a view, written as 16-bit words while a view has <= 65536 tiles)" : "",
           (int)cfg.useMask, (int)cfg.useAbsGrad, (int)cfg.mipAntiliased, (int)cfg.visibleAdam, (int)cfg.singleCamera, (int)cfg.progressiveTrain, world);
     std::string ign;
     if (cfg.modelType != 0) ign += " modelType(only 3DGS)";
