@@ -153,7 +153,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
                 const uint32_t* __restrict__ live_splat /*k_render_fwd's compacted lists (entries that reach the tile), or null*/,
                 const uint32_t* __restrict__ live_pos /*list position -> position in the compacted list*/) {
     __shared__ TrLds<BK> L;
-    __shared__ float s_tab[4][(BK + 1) * 12];               // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
+    __shared__ __attribute__((aligned(16))) float s_tab[4][(BK + 1) * 12];   // per wave and batch entry: the 12-float row; row BK = sink of the dummy entry
     __shared__ __attribute__((aligned(16))) float s_tb[4][TR_SLOTS * TR_SS];  // per wave: slot, plane (v5 | w), phase-1 lane
     (void)bg_arg;
     const int dbg = DVS_DBG_VALUE;                          // release builds: 0, every `dbg &` test below folds away
@@ -179,12 +179,23 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
     const int X0 = tx * DVS_TILE + 4 * bx2, Y0 = ty * DVS_TILE + 4 * by2 + r2;
     const float X0f = (float)X0, Y0f = (float)Y0;
     float d2[4][3];                                           // upstream gradient of the four pixels (X0 + x, Y0) this lane sums in phase 2
-#pragma unroll                                                // (measured: fetching them per round instead — three global loads, or twelve
-    for (int x = 0; x < 4; ++x) {                             //  ds_bpermute from the phase-1 lanes — doubles the cost of a round)
-        const bool in2 = X0 + x < W && Y0 < H;
-        const size_t q = (size_t)Y0 * W + X0 + x;
+    // (measured: fetching them per round instead — three global loads, or twelve ds_bpermute from the phase-1 lanes — doubles the cost of a round)
+    if ((W & 3) == 0) {                                       // the four pixels are one aligned 16-B word per channel: 3 loads instead of 12
+        const bool in2 = X0 < W && Y0 < H;                    // (X0 and W are multiples of 4: all four pixels are inside, or none)
+        const size_t q = (size_t)Y0 * W + X0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) d2[x][c] = in2 ? dL_dout[c * P + q] : 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float4 v = in2 ? *reinterpret_cast<const float4*>(dL_dout + c * P + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d2[0][c] = v.x; d2[1][c] = v.y; d2[2][c] = v.z; d2[3][c] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const bool in2 = X0 + x < W && Y0 < H;
+            const size_t q = (size_t)Y0 * W + X0 + x;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d2[x][c] = in2 ? dL_dout[c * P + q] : 0.f;
+        }
     }
     const int perm_r = (r2 == 1) ? 2 : (r2 == 2) ? 1 : r2;    // value index inside each packed register after the two swaps
     const int xaddr = (lane ^ 32) << 2;
@@ -206,7 +217,7 @@ k_render_bwd_tr(ViewBg bg_arg /* MUST stay the first parameter: read through dvs
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, d, 64));
     if (pi == 0) L.blast[blk1] = bmax;
-    for (int e = threadIdx.x; e < 4 * (BK + 1) * 12; e += RB) (&s_tab[0][0])[e] = 0.f;
+    for (int e = threadIdx.x; e < (BK + 1) * 12; e += RB) reinterpret_cast<float4*>(&s_tab[0][0])[e] = make_float4(0.f, 0.f, 0.f, 0.f);      // (4 tables x (BK + 1) x 12 floats = (BK + 1) x 12 16-B words)
     if (threadIdx.x < 16) L.list[threadIdx.x] = (uint8_t)BK;
 #ifdef TR_STATS
     if (threadIdx.x < BK) L.live[threadIdx.x] = 0u;
