@@ -15,7 +15,7 @@
 #include "dvs_kernels.h"
 
 #ifndef PP_BLOCK
-#define PP_BLOCK 256
+#define PP_BLOCK 128
 #endif
 
 // ---- cooperative row staging: rows of RW floats per splat, block of PP_BLOCK splats ---------------
