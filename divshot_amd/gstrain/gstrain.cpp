@@ -74,7 +74,7 @@ struct Lcg {       // tiny deterministic noise source for the synthetic initiali
 };
 }  // namespace
 
-struct GaussianTrainerScene::Impl {
+struct __attribute__((visibility("hidden"))) GaussianTrainerScene::Impl {     // the class is exported (GSTRAIN_API), its implementation is not
     GaussianTrainConfig cfg;
     int loadItr = -1;
     TrainingStatus status = TrainingStatus::Loading_Prepare;

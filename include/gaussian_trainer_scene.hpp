@@ -9,6 +9,12 @@
 // Because the config crosses dlsym() by const reference and carries std::string members, host and plugin must be
 // built against THIS header with the same C++ standard library (SURVEY.md §7 "ABI of GaussianTrainConfig").
 #pragma once
+// GSTRAIN_API marks what libgstrain.so exports: the class the editor constructs itself (editor.cpp:2023
+// add_component<GaussianTrainerScene>(trainConfig, -1)) with its CPU getters (editor.cpp:1459-1473), the two free probes
+// (editor.cpp:1534,1539) and the C symbols the CLI resolves by dlsym. Everything else in the plugin is built -fvisibility=hidden.
+#ifndef GSTRAIN_API
+#define GSTRAIN_API __attribute__((visibility("default")))
+#endif
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -63,7 +69,7 @@ struct GaussianTrainConfig {
     int viewsPerIter = 1;
 };
 
-class GaussianTrainerScene {
+class GSTRAIN_API GaussianTrainerScene {
 public:
     enum class TrainingStatus { Loading_Prepare, Colmap_Sfm, Preprocess_Done, Training, Training_Done, Loading_Failed, GS2Mesh };
 
@@ -125,20 +131,20 @@ private:
 };
 
 // free functions the editor calls before it starts training (editor.cpp:1534,1539)
-bool is_device_support_gstrain();     // a gfx950-class HIP device is visible
-bool is_driver_support();             // the HIP runtime initialises
+GSTRAIN_API bool is_device_support_gstrain();     // a gfx950-class HIP device is visible
+GSTRAIN_API bool is_driver_support();             // the HIP runtime initialises
 
 // C symbols the hosts resolve with dlsym (gs_train.cpp:24,105-109,144-150,178; plugin.cpp:89-111)
 extern "C" {
-void  gstrain_init();
-void* create_splat(const GaussianTrainConfig& config, int loadItr);
-bool  load_train_data(GaussianTrainerScene* scene, const std::string& path);
-void  train_step(GaussianTrainerScene* scene);
-int   get_cur_step(GaussianTrainerScene* scene);
-void  save_splat_model(GaussianTrainerScene* scene);
-void  export_mesh(GaussianTrainerScene* scene);
-void  delete_splat(GaussianTrainerScene* scene);
-void  gstrain_destroy();
-const char* get_description();
-void* create_instance();
+GSTRAIN_API void  gstrain_init();
+GSTRAIN_API void* create_splat(const GaussianTrainConfig& config, int loadItr);
+GSTRAIN_API bool  load_train_data(GaussianTrainerScene* scene, const std::string& path);
+GSTRAIN_API void  train_step(GaussianTrainerScene* scene);
+GSTRAIN_API int   get_cur_step(GaussianTrainerScene* scene);
+GSTRAIN_API void  save_splat_model(GaussianTrainerScene* scene);
+GSTRAIN_API void  export_mesh(GaussianTrainerScene* scene);
+GSTRAIN_API void  delete_splat(GaussianTrainerScene* scene);
+GSTRAIN_API void  gstrain_destroy();
+GSTRAIN_API const char* get_description();
+GSTRAIN_API void* create_instance();
 }

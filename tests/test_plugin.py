@@ -64,6 +64,88 @@ def test_kat5_ply_wire_format(plugin, tmp_path):
         assert np.array_equal(A[k], B[k]), k
 
 
+HOST_SRC = os.path.join(ROOT, "tests", "hosts", "editor_like.cpp")
+
+
+def build_editor_like(dst):
+    """The editor-like host links libgstrain DIRECTLY (no dlsym): the class, its getters and the two free probes must be exported."""
+    exe = os.path.join(str(dst), "editor_like")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), HOST_SRC, "-o", exe, "-L", LIB, "-lgstrain",
+                           "-Wl,-rpath," + LIB, "-Wl,-rpath-link," + LIB])
+    return exe
+
+
+def test_cpp_trainer_surface_is_exported(plugin, tmp_path):
+    """SURVEY §8(f) rank 4 / VERDICT r05 item 1: the reference's second host constructs GaussianTrainerScene itself (editor.cpp:2023) and
+    calls its methods (editor.cpp:1459-1473, inspector_panel.cpp:765-1000) — every public member function the header declares, the two
+    free probes (editor.cpp:1534,1539) and the C symbols are dynamic symbols of libgstrain.so; the implementation struct and the PLY
+    code are not. The exported set is pinned: additions are deliberate."""
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", PLUGIN]).decode()
+    syms = [l.split(None, 2)[2] for l in out.splitlines() if len(l.split(None, 2)) == 3 and l.split(None, 2)[1] in "TWV"]
+    methods = sorted({re.match(r"GaussianTrainerScene::(~?\w+)", s_).group(1) for s_ in syms if s_.startswith("GaussianTrainerScene::")})
+    hdr = open(os.path.join(ROOT, "include", "gaussian_trainer_scene.hpp")).read()
+    body = re.sub(r"//[^\n]*", "", hdr[hdr.index("class GSTRAIN_API GaussianTrainerScene"):hdr.index("private:")])
+    declared = sorted(set(re.findall(r"(~?\b[A-Za-z_]\w*)\s*\([^;{]*\)\s*(?:const)?\s*;", body)) - {"operator"})
+    assert "getGaussianSHNCpu" in declared and "GaussianTrainerScene" in declared and "~GaussianTrainerScene" in declared and len(declared) >= 40
+    assert methods == declared, (sorted(set(declared) - set(methods)), sorted(set(methods) - set(declared)))
+    free = sorted(s_.split("(")[0] for s_ in syms if not s_.startswith("GaussianTrainerScene::") and "Impl" not in s_
+                  and not s_.startswith(("typeinfo", "vtable", "std::", "void std::", "guard variable")))
+    assert free == sorted(["gstrain_init", "create_splat", "load_train_data", "train_step", "get_cur_step", "save_splat_model", "export_mesh",
+                           "delete_splat", "gstrain_destroy", "get_description", "create_instance", "gstrain_write_ply", "gstrain_read_ply",
+                           "is_device_support_gstrain", "is_driver_support"]), free
+    assert not any("::Impl::" in s_ or "gsply" in s_ for s_ in syms)
+    # and a host that links the class directly builds; without a device it refuses loudly (no CPU path)
+    exe = build_editor_like(tmp_path)
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe, "synthetic:N=100,W=64,H=64,cams=2,sh=1,seed=1", str(tmp_path / "m"), "1", "1", str(tmp_path / "d")], capture_output=True, text=True)
+        assert p.returncode == 3 and "no supported device" in p.stderr
+
+
+def read_editor_dump(path):
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[:8], np.int64)[0])
+    a = np.frombuffer(raw[8:], np.float32)
+    assert a.size == n * 59, (a.size, n)
+    out, o = {}, 0
+    for k, w in (("pos", 3), ("sh0", 3), ("shN", 45), ("opacity", 1), ("scale", 3), ("rot", 4)):       # the dump's order, not the PLY's
+        out[k] = a[o:o + n * w].reshape(n, w); o += n * w
+    return n, out
+
+
+@pytest.mark.gpu
+def test_editor_like_host_pulls_the_model_through_the_getters(plugin, tmp_path):
+    """The trainer -> viewer hand-off of editor.cpp:1459-1473 -> GaussianModel::update_from_cpu (gaussian_model.cpp:43-68): a host linked
+    against libgstrain constructs the class with (cfg, -1), loads, trains across an ADC refinement (so that N changes), pulls the six arrays
+    with the editor's byte counts (12 / 16 / 12 / 4 / 12 / 180 B per splat) and saves. What the viewer-side container received equals the
+    PLY of the same iteration BIT FOR BIT — in particular shs_n[j*3+c] after the un-tiling of the training layout (DVS_SHN_TILED)."""
+    exe = build_editor_like(tmp_path)
+    model, dump = str(tmp_path / "m" / "iteration"), str(tmp_path / "dump")
+    p = subprocess.run([exe, "synthetic:N=6000,W=192,H=128,cams=6,sh=3,seed=11", model, "7", "8", dump], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    m = re.search(r"splats (\d+) -> (\d+) -> (\d+), iterations (\d+), loss ([0-9.eE+-]+), status (\d+)", p.stdout)
+    assert m, p.stdout
+    n0, n1, n2, its = (int(m.group(k)) for k in range(1, 5))
+    assert n0 == n1 == 6000 and n2 != n1 and its == 15 and float(m.group(5)) > 0, p.stdout      # the refinement at iteration 10 changed N
+    plugin.gstrain_read_ply.restype = C.c_int64
+    plugin.gstrain_read_ply.argtypes = [C.c_char_p] + [C.c_void_p] * 6 + [C.c_uint64]
+    order = ("pos", "sh0", "shN", "opacity", "scale", "rot")
+    for tag, it, n_want in (("a", 7, n1), ("b", 15, n2)):
+        n, got = read_editor_dump(f"{dump}_{tag}.bin")
+        assert n == n_want
+        ply = {k: np.zeros_like(got[k]) for k in order}
+        assert plugin.gstrain_read_ply(f"{model}_{it}.ply".encode(), *[ply[k].ctypes.data for k in order], n) == n
+        for k in order:
+            assert np.array_equal(got[k].view(np.uint32), ply[k].view(np.uint32)), (tag, k)
+        assert np.abs(got["shN"]).max() > 0 and np.isfinite(got["shN"]).all()
+        # the raw file agrees too: f_rest[c*15+j] on disk = shs_n[j*3+c] in the viewer (tiny_gsplat.cpp:231-236, gaussian_model.cpp:163-167)
+        raw = open(f"{model}_{it}.ply", "rb").read().split(b"end_header\n", 1)[1]
+        row = np.frombuffer(raw, np.float32).reshape(n, 59)
+        assert np.array_equal(row[:, 6:51].reshape(n, 3, 15), got["shN"].reshape(n, 15, 3).transpose(0, 2, 1))
+    a, b = read_editor_dump(dump + "_a.bin")[1], read_editor_dump(dump + "_b.bin")[1]
+    assert not np.array_equal(a["pos"][:100], b["pos"][:100]) or n2 != n1                        # the getters are not serving a stale copy
+
+
 @pytest.mark.gpu
 def test_cli_trains_synthetic_scene(tmp_path):
     """The host sequence init -> create -> load -> {get_cur_step, train_step}* -> save -> delete -> destroy, end to end."""
