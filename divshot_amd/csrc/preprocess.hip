@@ -299,13 +299,20 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     }   // views
 }
 
-// The view-dependent geometry part of A9 for one (splat, view): recomputes the forward intermediates (same expressions as
-// k_preprocess_fwd), turns the A8 moments into dL/dmean2D and dL/dconic, and walks back through conic -> cov2D -> (J, W) -> Sigma ->
-// (scale, rotation) and through the projection to the position. `gp` arrives holding the SH view-direction part and leaves holding the
-// complete dL/dpos of this view (the order of the additions is the order of the fused kernel of round 1: results are bit-identical).
+// The geometry part of A9. Round 6 splits it where the chain stops depending on the view:
+//   a9_geometry   per (splat, view): recomputes the forward intermediates (same expressions as k_preprocess_fwd: these feed nothing but
+//                 floats here, but the conic must be the one the forward composited with), turns the A8 moments into dL/dmean2D and
+//                 dL/dconic, walks back through conic -> cov2D -> (J, W) and through the projection to the position, and ADDS the
+//                 view's symmetrised dL/dSigma (Gm + Gm^T, six values) to `Gs`;
+//   a9_sigma_to_params   once per splat: Sigma = M M^T, M = R S  ->  dL/dscale, dL/drot. The 3D covariance does not depend on the view
+//                 and this step is linear in dL/dSigma, so a multi-view pass runs it ONCE on the sum over its views instead of once
+//                 per view (27 + 9 + 32 multiply-adds and the quaternion normalisation leave the view loop; k_preprocess_bwd_views is
+//                 bound by its vector instructions once its loads are pipelined, profiles/r06_a9_ab.txt).
+// The backward-only blocks allow FMA contraction (this file is compiled with -ffp-contract=off for A2's bit-exact bins; nothing below
+// the conic feeds an integer decision). `gp` arrives holding the SH view-direction part and leaves holding the complete dL/dpos.
 __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float py, float pz, float in_s0, float in_s1, float in_s2, float4 in_q,
                                             float in_op, uint32_t fl, float4 r0, float4 r1, int antialias, int grad_mode, float gp[3],
-                                            float gsc[3], float gq_out[4], float& g_op, float2& dm_out) {
+                                            float Gs[6] /* += : 00 01 02 11 12 22 of Gm + Gm^T */, float& g_op, float2& dm_out) {
         const float tx = dvs_xform(cam.view, px, py, pz, 0);
         const float ty = dvs_xform(cam.view, px, py, pz, 1);
         const float tz = dvs_xform(cam.view, px, py, pz, 2);
@@ -348,13 +355,16 @@ __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float p
         // A8 publishes moments of s = dL/dG * G about the mean (S_x S_y | S_xx S_xy S_yy | S_o); with the conic (A, B, C) — the same
         // expressions, hence the same bits, as the forward wrote — they become the gradients of the 2D mean and of the conic
         const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+        const float sig = dvs_sigmoid_det(in_op);
+        (void)ty;
+    {
+#pragma clang fp contract(fast)
         const float2 dL_dm = make_float2(-(cA * r0.x + cB * r0.y), -(cC * r0.y + cB * r0.x));
         const float4 gco = make_float4(-0.5f * r0.z, -r0.w, -0.5f * r1.x, r1.y);
         dm_out = dL_dm;
 
         // 2. opacity (+ AA)
         float g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f;
-        const float sig = dvs_sigmoid_det(in_op);
         float g_sig = gco.w;
         if (antialias) {
             const float det_orig = cxx * cyy - b * b;
@@ -381,13 +391,20 @@ __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float p
             g_cyy += gco.x * det_inv + g_det * a;
             g_cxy += -gco.y * det_inv + g_det * (-2.f * b);
         }
-        // 4. cov2D
-        float Gm[9];
+        // 4. cov2D = T Sigma T^T: dL/dSigma = Gm with Gm[r][q] = g_cxx T0r T0q + g_cxy T0r T1q + g_cyy T1r T1q; only its symmetric part
+        //    acts on Sigma = M M^T:  (Gm + Gm^T)[r][q] = T0q U_r + T1q W_r  with  U = 2 g_cxx T0 + g_cxy T1,  W = g_cxy T0 + 2 g_cyy T1
+        {
+            const float a2 = 2.f * g_cxx, c2 = 2.f * g_cyy;
+            float U[3], Wv[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                Gm[r * 3 + q] = (g_cxx * T0[r] * T0[q] + g_cxy * T0[r] * T1[q]) + g_cyy * T1[r] * T1[q];
+            for (int r = 0; r < 3; ++r) { U[r] = a2 * T0[r] + g_cxy * T1[r]; Wv[r] = g_cxy * T0[r] + c2 * T1[r]; }
+            Gs[0] += T0[0] * U[0] + T1[0] * Wv[0];
+            Gs[1] += T0[1] * U[0] + T1[1] * Wv[0];
+            Gs[2] += T0[2] * U[0] + T1[2] * Wv[0];
+            Gs[3] += T0[1] * U[1] + T1[1] * Wv[1];
+            Gs[4] += T0[2] * U[1] + T1[2] * Wv[1];
+            Gs[5] += T0[2] * U[2] + T1[2] * Wv[2];
+        }
         float gT0[3], gT1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -422,8 +439,22 @@ __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float p
             for (int k = 0; k < 3; ++k)
                 gp[k] += (cam.proj[k * 4 + 0] * g_hx + cam.proj[k * 4 + 1] * g_hy) + cam.proj[k * 4 + 3] * g_hw;
         }
-        (void)ty;
-        // 7. Sigma = M M^T
+    }
+}
+
+// 7. Sigma = M M^T with M = R S: dL/dM = (Gm + Gm^T) M, then scale and rotation (the quaternion is normalised in the forward, so its
+// gradient is projected off the quaternion and divided by its norm). `Gs` = the symmetrised dL/dSigma summed over the views.
+__device__ __forceinline__ void a9_sigma_to_params(float in_s0, float in_s1, float in_s2, float4 in_q, const float Gs[6], float gsc[3],
+                                                   float gq_out[4]) {
+    const float s[3] = {dvs_exp_det(in_s0), dvs_exp_det(in_s1), dvs_exp_det(in_s2)};
+    const float qn = dvs_sqrt_rn(((in_q.x * in_q.x + in_q.y * in_q.y) + in_q.z * in_q.z) + in_q.w * in_q.w);
+    const float inv_qn = 1.0f / qn;
+    const float qr = in_q.x * inv_qn, qx = in_q.y * inv_qn, qy = in_q.z * inv_qn, qz = in_q.w * inv_qn;
+    float R[9];
+    dvs_quat_to_rot(qr, qx, qy, qz, R);
+    {
+#pragma clang fp contract(fast)
+        const float G[9] = {Gs[0], Gs[1], Gs[2], Gs[1], Gs[3], Gs[4], Gs[2], Gs[4], Gs[5]};
         float M[9], gM[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -435,7 +466,7 @@ __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float p
             for (int k = 0; k < 3; ++k) {
                 float acc = 0.f;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) acc += (Gm[r * 3 + q] + Gm[q * 3 + r]) * M[q * 3 + k];
+                for (int q = 0; q < 3; ++q) acc += G[r * 3 + q] * M[q * 3 + k];
                 gM[r * 3 + k] = acc;
             }
         float gR[9];
@@ -454,6 +485,7 @@ __device__ __forceinline__ void a9_geometry(const DvsCam& cam, float px, float p
         const float qg = ((qr * gq[0] + qx * gq[1]) + qy * gq[2]) + qz * gq[3];
         gq_out[0] = (gq[0] - qr * qg) * inv_qn; gq_out[1] = (gq[1] - qx * qg) * inv_qn;
         gq_out[2] = (gq[2] - qy * qg) * inv_qn; gq_out[3] = (gq[3] - qz * qg) * inv_qn;
+    }
 }
 
 // ---- A9 ---------------------------------------------------------------------------------------
@@ -589,7 +621,9 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
             gp[0] += (gdir[0] - ux * ug) * inv_dl; gp[1] += (gdir[1] - uy * ug) * inv_dl; gp[2] += (gdir[2] - uz * ug) * inv_dl;
         }
 
-        a9_geometry(cam, px, py, pz, in_s0, in_s1, in_s2, in_q, in_op, fl, r0, r1, antialias, grad_mode, gp, gsc, gq_out, g_op, dm_out);
+        float Gs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        a9_geometry(cam, px, py, pz, in_s0, in_s1, in_s2, in_q, in_op, fl, r0, r1, antialias, grad_mode, gp, Gs, g_op, dm_out);
+        a9_sigma_to_params(in_s0, in_s1, in_s2, in_q, Gs, gsc, gq_out);
     } else if (valid) {
         if (TILED) {
             if (g4 && !ACCUM) {
@@ -654,7 +688,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 // all-gather of dcolor (the factorised exchange), with the same kernel. Per view the same expressions in the same order as
 // k_preprocess_bwd, so the geometry gradients of a batch are bit-identical to its views run one by one with opts.accumulate.
 template <bool ACCUM, bool NOHOIST>
-__global__ void __launch_bounds__(PP_BLOCK)
+__global__ void __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read through dvs_load_cam() */, int n_views, int n,
                        const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
                        const float* __restrict__ scale, const float* __restrict__ rot, int deg, int antialias,
@@ -676,30 +710,62 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
     const float in_op = opacity[il];
     const float4* p4 = reinterpret_cast<const float4*>(shN);
     float gp[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    float Gs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // dL/dSigma (symmetrised), summed over the views
     float g_op = 0.f;
     float2 ag = make_float2(0.f, 0.f), dm = make_float2(0.f, 0.f);
     // which views see the splat: all radii are requested up front, so that a view costs ONE dependent memory round trip (its rows
-    // and flags) instead of two (radius, then rows) — the kernel is latency-bound at two waves per SIMD
+    // and flags) instead of two (radius, then rows)
     uint32_t vis = 0;
     for (int view = 0; view < n_views; ++view) vis |= (valid && radii[(int64_t)view * n + il] > 0) ? (1u << view) : 0u;
+    // Round 6: the kernel was latency-bound (two waves per SIMD, every view one dependent HBM round trip plus twelve dependent L2 reads
+    // of the SH coefficients; 57 % vector-ALU-busy at 4.2 TB/s, profiles/r05b_pmc_sq.txt). Two changes, neither touches an expression:
+    //  (i) the 45 higher-order coefficients are read ONCE, before the view loop, and stay in 48 registers (the loop used to re-read
+    //      them from L2 for every view: 1.26 GB of L2 traffic per 8-view step, and — vector memory returns in order — every wait for
+    //      them was also a wait for anything requested earlier);
+    //  (ii) the view loop is software-pipelined: view v+1's three 16-B rows and flags are requested before view v's arithmetic,
+    //      so the round trip runs under ~850 vector instructions instead of in front of them.
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = z4, n1 = z4, n2 = z4;
+    uint32_t nfl = 0;
+    {   // (unconditional loads: a lane without work reads element 0 — one shared line — so that no branch, and with it no register
+        // copy behind the load, i.e. no wait, sits between a request and its use one iteration later.
+        // The first view's rows are requested whether or not the splat is visible there: they then do not wait for the radii.)
+        const int64_t o = (int64_t)il;
+        n0 = grad_rows[3 * o]; n1 = grad_rows[3 * o + 1]; n2 = grad_rows[3 * o + 2];
+        nfl = flags[o];
+    }
+    // the coefficients are requested BEHIND the first view's rows (vector memory returns in order) and the loop body takes the geometry
+    // chain, which does not need them, first: in a one-view launch the 192 B per splat arrive under that arithmetic
+    float4 q4[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) q4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (deg > 0) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) q4[c] = p4[shn_tiled_f4(il, c)];
+    }
 
     for (int view = 0; view < n_views; ++view) {
         const DvsCam cam = dvs_load_cam(view);
         const int64_t o = (int64_t)view * n + il;
+        const float4 r0 = n0, r1 = n1, r2 = n2;
+        const uint32_t fl = nfl;
+        {
+            const int64_t on = (view + 1 < n_views && ((vis >> (view + 1)) & 1u)) ? o + n : 0;
+            n0 = grad_rows[3 * on]; n1 = grad_rows[3 * on + 1]; n2 = grad_rows[3 * on + 2];
+            nfl = flags[on];
+        }
         // NOHOIST: keep the view-independent intermediates (exp of the scales, rotation, 3D covariance) from being hoisted out of the
         // loop — they are cheap to recompute and would otherwise stay live across it
         float s0_ = in_s0, s1_ = in_s1, s2_ = in_s2, q0_ = in_q.x, q1_ = in_q.y, q2_ = in_q.z, q3_ = in_q.w, op_ = in_op;
         if (NOHOIST) asm volatile("" : "+v"(s0_), "+v"(s1_), "+v"(s2_), "+v"(q0_), "+v"(q1_), "+v"(q2_), "+v"(q3_), "+v"(op_));
         float gcol[3] = {0.f, 0.f, 0.f};
         if ((vis >> view) & 1u) {
-            const float4 r0 = grad_rows[3 * o], r1 = grad_rows[3 * o + 1], r2 = grad_rows[3 * o + 2];
-            if (rezero) {
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                grad_rows[3 * o] = z4; grad_rows[3 * o + 1] = z4; grad_rows[3 * o + 2] = z4;
-            }
-            const uint32_t fl = flags[o];
+            if (rezero) { grad_rows[3 * o] = z4; grad_rows[3 * o + 1] = z4; grad_rows[3 * o + 2] = z4; }
+            float gpv[3] = {0.f, 0.f, 0.f}, g_opv;
+            float2 dmv;
+            a9_geometry(cam, px, py, pz, s0_, s1_, s2_, make_float4(q0_, q1_, q2_, q3_), op_, fl, r0, r1, antialias, grad_mode, gpv, Gs, g_opv, dmv);
             const float dL_dcol[3] = {r1.z, r1.w, r2.x};
-            // 1. colour -> view direction (same expressions and order as k_preprocess_bwd; the SH rows themselves: k_sh_grad_combine)
+            // colour -> view direction (the SH rows themselves: k_sh_grad_combine)
             const float dxw = px - cam.campos[0], dyw = py - cam.campos[1], dzw = pz - cam.campos[2];
             const float dl = dvs_sqrt_rn((dxw * dxw + dyw * dyw) + dzw * dzw);
             const float inv_dl = 1.0f / dl;
@@ -711,42 +777,26 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
             float gc[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { gc[ch] = (fl & (1u << ch)) ? 0.f : dL_dcol[ch]; gcol[ch] = gc[ch]; }
-            // The coefficients come from the tiled array again for every view (after the first view they are L2 hits; keeping 48 of
-            // them in registers across the loop would cost more registers than there are). They are requested in three groups of
-            // four 16-B chunks, unconditionally: a9_dir_grad does not read the sums of the bands above `deg` — a
-            // test per chunk made every chunk its own dependent L2 round trip (12 per view in a latency-bound kernel).
-            if (deg > 0) {
+            // (a9_dir_grad does not read the sums of the bands above `deg`; with deg == 0 the coefficient registers hold zeros)
 #pragma unroll
-                for (int g4 = 0; g4 < 3; ++g4) {
-                    float4 q4[4];
+            for (int c = 0; c < 12; ++c) {
+                const float qv[4] = {q4[c].x, q4[c].y, q4[c].z, q4[c].w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) q4[c] = p4[shn_tiled_f4(i, g4 * 4 + c)];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float qv[4] = {q4[c].x, q4[c].y, q4[c].z, q4[c].w};
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int e = (g4 * 4 + c) * 4 + u;              // compile-time: coefficient k = e/3 + 1, channel e%3
-                            if (e < 45) {
-                                const int k = e / 3 + 1, ch = e % 3;
-                                sk[k] = __builtin_fmaf(qv[u], gc[ch], sk[k]);
-                            }
-                        }
+                for (int u = 0; u < 4; ++u) {
+                    const int e = c * 4 + u;                                 // compile-time: coefficient k = e/3 + 1, channel e%3
+                    if (e < 45) {
+                        const int k = e / 3 + 1, ch = e % 3;
+                        sk[k] = __builtin_fmaf(qv[u], gc[ch], sk[k]);
                     }
                 }
             }
-            float gpv[3] = {0.f, 0.f, 0.f}, gscv[3], gqv[4], g_opv;
-            float2 dmv;
             {
                 a9_dir_grad(deg, ux, uy, uz, sk, gdir);
                 const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
                 gpv[0] += (gdir[0] - ux * ug) * inv_dl; gpv[1] += (gdir[1] - uy * ug) * inv_dl; gpv[2] += (gdir[2] - uz * ug) * inv_dl;
             }
-            a9_geometry(cam, px, py, pz, s0_, s1_, s2_, make_float4(q0_, q1_, q2_, q3_), op_, fl, r0, r1, antialias, grad_mode, gpv, gscv, gqv, g_opv, dmv);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { gp[k] += gpv[k]; gsc[k] += gscv[k]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) gq[k] += gqv[k];
+            for (int k = 0; k < 3; ++k) gp[k] += gpv[k];
             g_op += g_opv;
             ag.x += r2.y; ag.y += r2.z;
             dm.x += dmv.x; dm.y += dmv.y;
@@ -760,6 +810,7 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
         }
     }
 
+    if (vis) a9_sigma_to_params(in_s0, in_s1, in_s2, in_q, Gs, gsc, gq);       // once per splat: linear in the summed dL/dSigma
     if (valid) {
         if (out_absgrad2d) {
             float2 a = ag;
