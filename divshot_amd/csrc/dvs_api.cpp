@@ -47,6 +47,10 @@ struct Buf {
         if (e != hipSuccess) { e = hipMalloc(&p, need); want = need; }
         if (e != hipSuccess) { set_error("hipMalloc", e, __FILE__, __LINE__); p = nullptr; return DVS_ERR_HIP; }
         bytes = want;
+#ifdef DVS_EXPERIMENT
+        // timing-only ablation builds (tools/xbuild.sh) may skip stores: zeroed arenas keep every index a later kernel gathers through valid
+        (void)hipMemset(p, 0, want);
+#endif
         return DVS_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -76,6 +80,7 @@ struct dvs_ctx {
     uint32_t* live_pos = nullptr;
     bool live_lists = true;              // env DVS_LIVE_LISTS=0: A8 walks the full lists (A/B and parity of the two routes)
     Buf tmp_keys, tmp_vals;
+    int fe_rank_atomic = 0;              // the sorts' scatters rank by returning LDS adds (frontend.hip): the device passed dvs_fe_probe_rank_atomic
     Buf ranges_canon;                    // (start, end) per tile as k_render_fwd decodes them when A6 rides on the tile sort (frontend.hip)
     Buf ranges, final_T, n_contrib;      // `ranges` starts with the front end's zeroed words (fe_zero_bytes), the tile ranges follow: ONE memset per forward
     // the binning front end (frontend.hip): every view is a segment of the sorts
@@ -237,6 +242,23 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
         return nullptr;
     }
     c->total_host[0] = c->total_host[1] = c->total_host[2] = c->total_host[3] = 0;   // [0] T  [1] arena overflows
+    {   // how the sorts' scatters rank inside a wave (frontend.hip): returning LDS adds, if this device serves the lanes of one address in
+        // lane order — probed once per process and device, on the device; DVS_FE_RANK=ballot keeps the multisplit of rounds 2-5
+        static int probed[64];                    // 0 unknown, 1 lane-ordered, 2 not
+        const char* mode = getenv("DVS_FE_RANK");
+        if (mode && mode[0] == 'b') c->fe_rank_atomic = 0;
+        else {
+            if (device < 64 && probed[device] == 0) {
+                uint32_t bad = 1u;
+                uint32_t* word = nullptr;
+                if (hipMalloc((void**)&word, 4) == hipSuccess && hipMemset(word, 0, 4) == hipSuccess && dvs_fe_probe_rank_atomic(nullptr, word) == hipSuccess &&
+                    hipMemcpy(&bad, word, 4, hipMemcpyDeviceToHost) == hipSuccess)
+                    probed[device] = bad == 0u ? 1 : 2;
+                if (word) (void)hipFree(word);
+            }
+            c->fe_rank_atomic = (device < 64 && probed[device] == 1) ? 1 : 0;
+        }
+    }
     if (const char* v = getenv("DVS_ASYNC")) c->async_T = v[0] == '1';
     if (ensure_frontend_arenas(c) != DVS_OK ||
         ensure_splat_arenas(c, max_splats * (size_t)max_views) != DVS_OK || ensure_image_arenas(c, max_w, max_h, max_views) != DVS_OK ||
@@ -330,7 +352,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
                 c->fe_seg_n = n; c->fe_seg_V = V; c->fe_seg_rows = rows;
             }
             HIPCHECK(dvs_launch_depth_sort(st, n, V, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
-                                           fe_seg_all(c), fe_seg_vis(c), fe_kred(c), c->fe_hist.as<uint32_t>(), fe_totals(c)));
+                                           fe_seg_all(c), fe_seg_vis(c), fe_kred(c), c->fe_hist.as<uint32_t>(), fe_totals(c), c->fe_rank_atomic));
         }
         size_t e2 = tm.mark(); tm.span("depth_sort", e1, e2);
         // A3: tile counts in depth order (the one random gather: the tile rectangles), the views' instance ranges; T stays on the device
@@ -373,7 +395,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
             HIPCHECK(dvs_launch_seg_sort(st, V, c->inst_tile[0].as<uint32_t>(), c->inst_splat[0].as<uint32_t>(), c->inst_tile[1].as<uint32_t>(),
                                          c->inst_splat[1].as<uint32_t>(), fe_seg_tile(c), 0, tiles > 1 ? bits_for((uint32_t)(tiles - 1)) : 1,
                                          c->async_T ? (T_expected ? T_expected : c->inst_cap) : T, tile_part, nbtot, c->fe_hist.as<uint32_t>(), fe_totals(c),
-                                         (uint32_t)tiles, &icur, fuse_a6 ? ranges_ptr(c) : nullptr, write_keys ? 1 : 0, key16));
+                                         (uint32_t)tiles, &icur, fuse_a6 ? ranges_ptr(c) : nullptr, write_keys ? 1 : 0, key16, c->fe_rank_atomic));
         }
         size_t e6 = tm.mark(); tm.span("tile_sort", e5, e6);
         if (fuse_a6) ranges_encoded = n > 0 ? 1 : 0;
@@ -670,7 +692,7 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
         HIPCHECK(dvs_launch_seg_init(st, (int)n, 1, 0, fe_seg_all(c)));      // one segment: [0, n)
         c->fe_seg_n = -1;                                                    // (the forward's descriptors are gone)
         HIPCHECK(dvs_launch_seg_sort(st, 1, k[0], v[0], k[1], v[1], fe_seg_all(c), bit_lo, bit_hi - bit_lo, n, part, (uint32_t)(n / part) + 3u,
-                                     c->fe_hist.as<uint32_t>(), fe_totals(c), 0u, &cur));
+                                     c->fe_hist.as<uint32_t>(), fe_totals(c), 0u, &cur, nullptr, 1, 0, c->fe_rank_atomic));
     }
     if (cur == 1) {
         HIPCHECK(hipMemcpyAsync(keys, k[1], n * 4, hipMemcpyDeviceToDevice, st));
@@ -740,6 +762,8 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
     }
     return DVS_OK;
 }
+
+int dvs_get_sort_rank_mode(dvs_ctx* c) { return c ? c->fe_rank_atomic : -1; }
 
 int dvs_get_arena_info(dvs_ctx* c, uint64_t* cap, uint64_t* grows, uint64_t* last_T, uint64_t* overflows) {
     if (!c) { g_last_error = "dvs_get_arena_info: null context"; return DVS_ERR_INVALID; }

@@ -57,12 +57,15 @@ void dvs_fe_block_counts(int n, uint32_t* nbv, uint32_t* nsb);                 /
 hipError_t dvs_launch_seg_init(hipStream_t st, int n, int V, uint32_t rows_per_view, DvsSeg* seg_all);
 // A5 (depth): keys0 [V][n] (culled = 0xFFFFFFFF) -> vals1[v * n + j] = index of the j-th nearest visible splat of view v, j < seg_vis[v].count
 hipError_t dvs_launch_depth_sort(hipStream_t st, int n, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
-                                 DvsSeg* seg_all, DvsSeg* seg_vis, const uint32_t* kred, uint32_t* hist, uint32_t* totals /*[V][DVS_FE_MAXBINS]*/);
+                                 DvsSeg* seg_all, DvsSeg* seg_vis, const uint32_t* kred, uint32_t* hist, uint32_t* totals /*[V][DVS_FE_MAXBINS]*/,
+                                 int rank_atomic = 0 /*scatter ranks by returning LDS adds: only after dvs_fe_probe_rank_atomic passed*/);
 // stable LSD sort of every segment's pairs over the key bits [bit_lo, bit_lo + bits) (digits <= 9 bits); result in buffers *result_in
 hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
                                uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
                                int* result_in, uint32_t* ranges_enc = nullptr /*A6 fused into the last pass: tile ranges as (~start, end), see k_seg_scatter*/,
-                               int write_last_keys = 1, int first_keys16 = 0 /*keys0 holds 16-bit keys (A4's tile ids)*/);
+                               int write_last_keys = 1, int first_keys16 = 0 /*keys0 holds 16-bit keys (A4's tile ids)*/, int rank_atomic = 0);
+// runs the two in-wave rankings of k_seg_scatter side by side on synthetic digits; *bad_dev (zeroed) counts disagreements (frontend.hip)
+hipError_t dvs_fe_probe_rank_atomic(hipStream_t st, uint32_t* bad_dev);
 // stage 0 = A3 (tile counts in depth order, block / super sums) + the views' instance ranges (seg_tile, total_dev); stage 1 = A4
 hipError_t dvs_launch_seg_binning(hipStream_t st, int n, int V, int rect_fmt, const DvsSeg* seg_vis, DvsSeg* seg_tile, const uint32_t* sorted_ids,
                                   const uint32_t* rect, uint32_t* rect_sorted, uint32_t* block_sums, unsigned long long* super, uint32_t* superexcl,

@@ -171,6 +171,13 @@ k_seg_rowscan(uint32_t* __restrict__ hist, uint32_t nbtot, const DvsSeg* __restr
 // Scatter. Ranks are stable: within a wave by a ballot multisplit (fe_match + mbcnt), across the rounds of a wave by per-wave digit
 // counters in LDS (a wave's LDS operations execute in order: all peers read the counter before their leader rewrites it), across the
 // waves by the counters' prefix, across the partitions by the scanned histogram row.
+// Round 6, RANK_ATOMIC: the ablations of profiles/r06_scatter_ablation.txt put the tile scatter's 93 us at 23 (loads) + 55 (ranking,
+// scans, LDS staging) + 15 (stores): the multisplit's ~40 vector instructions per key and round were the largest single part. One
+// returning LDS add per key (ds_add_rtn_u32 on the key's per-wave counter) yields the same rank — old value = keys of the digit in
+// earlier rounds + lower lanes of this round — PROVIDED lanes that hit one address are served in ascending lane order. The ISA manual
+// does not promise that, so it is not assumed: dvs_fe_probe_rank_atomic() runs both rankings on adversarial digit patterns on the
+// device at context creation and the atomic form is used only when every rank agrees (DVS_FE_RANK=ballot forces the multisplit;
+// the parity suite — bit-exact against std::stable_sort — runs both). Tile scatter 93 -> 75 us, depth scatter 39 -> 29 us per pass.
 //   digits of <= 9 bits ("reorder"): the partition's keys are written to LDS in digit order first, then stored slot by slot —
 //       consecutive lanes hold consecutive keys of one digit, so a store instruction covers a few runs instead of 64 scattered dwords;
 //   wider digits: straight from the registers (a run would be two keys long).
@@ -183,7 +190,7 @@ template <int ITEMS> struct FeScatterLds {
     static constexpr int WORDS = (REORDER_WORDS > WIDE_WORDS ? REORDER_WORDS : WIDE_WORDS) + 8;
 };
 
-template <int ITEMS>
+template <int ITEMS, bool RANK_ATOMIC /*rank by returning LDS adds instead of the ballot multisplit (round 6)*/>
 __global__ void __launch_bounds__(FE_BLOCK) __attribute__((amdgpu_waves_per_eu(4)))      // (<= 128 VGPRs: the LDS allows four workgroups per CU)
 k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /*null: the value is the element's index in its segment*/,
               uint32_t* __restrict__ keys_out /*null: the keys are not needed any more*/, uint32_t* __restrict__ vals_out,
@@ -287,15 +294,28 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
         for (int r = 0; r < ITEMS; ++r) {
             const bool valid = i0 + (uint32_t)r * 64 <= ilast && !(cull && key[r] == FE_CULLED);
             const uint32_t d = ((key[r] - sub) >> shift) & dmask;
-            const uint64_t peers = fe_match(d, valid, b);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
             uint32_t prev = 0;
-            if (valid) {
-                prev = cnt16[wave * cstride + d];                       // in-order LDS: all peers read before the leader writes
-                if (below == 0) cnt16[wave * cstride + d] = (uint16_t)(prev + (uint32_t)__popcll(peers));
-                vmask |= 1u << r;
+            if constexpr (RANK_ATOMIC) {
+                // rank inside the wave = what the returning LDS add hands back: lanes that add to one address are served in lane order
+                // (checked against the ballot ranking by dvs_fe_probe_rank_atomic before a context selects this path), rounds in
+                // program order, so the old value IS (earlier rounds' count) + (lower lanes with the same digit). Two u16 counters
+                // share a word: a wave's counter stays below 64 * ITEMS, so the low half never carries into the high one.
+                if (valid) {
+                    const uint32_t old = atomicAdd(&lds[wave * (cstride >> 1) + (d >> 1)], (d & 1u) ? 0x10000u : 1u);
+                    prev = (d & 1u) ? (old >> 16) : (old & 0xFFFFu);
+                    vmask |= 1u << r;
+                }
+                rank[r] = prev;
+            } else {
+                const uint64_t peers = fe_match(d, valid, b);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+                if (valid) {
+                    prev = cnt16[wave * cstride + d];                       // in-order LDS: all peers read before the leader writes
+                    if (below == 0) cnt16[wave * cstride + d] = (uint16_t)(prev + (uint32_t)__popcll(peers));
+                    vmask |= 1u << r;
+                }
+                rank[r] = prev + below;
             }
-            rank[r] = prev + below;
             asm volatile("" : "+v"(rank[r]));          // materialise the sum here: otherwise prev, below and the counter's address stay live per key
         }
         __syncthreads();
@@ -389,6 +409,7 @@ struct FeSortLaunch {
     int items;                 // 8 / 16 keys per thread
     uint32_t grid_per_view;    // workgroups per view (the kernels stride over the partitions)
     uint32_t* hist; uint32_t nbtot; uint32_t* totals;
+    int rank_atomic;           // k_seg_scatter<.., true>: only after dvs_fe_probe_rank_atomic() said yes on this device
 };
 
 static hipError_t fe_launch_pass(const FeSortLaunch& L, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, DvsSeg* seg_in,
@@ -397,27 +418,26 @@ static hipError_t fe_launch_pass(const FeSortLaunch& L, const uint32_t* kin, con
     const dim3 grid(L.grid_per_view * (uint32_t)L.V), blk(FE_BLOCK);
     const int maxbins = adaptive ? FE_MAXBINS : (1 << bits);
     const dim3 rgrid((uint32_t)((maxbins + FE_WAVES - 1) / FE_WAVES) * (uint32_t)L.V);
-    if (L.items == 8) {
-        hipLaunchKernelGGL(k_seg_hist<8>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred, key16);
-        hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * 8), L.totals);
-        hipLaunchKernelGGL(k_seg_scatter<8>, grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits,
-                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, key16, ranges_enc);
-    } else {
-        hipLaunchKernelGGL(k_seg_hist<16>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred, key16);
-        hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * 16), L.totals);
-        hipLaunchKernelGGL(k_seg_scatter<16>, grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits,
-                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, key16, ranges_enc);
-    }
+#define FE_PASS(I, A)                                                                                                                          \
+    do {                                                                                                                                       \
+        hipLaunchKernelGGL(k_seg_hist<I>, grid, blk, 0, L.st, kin, seg_in, L.V, adaptive, pass, shift, bits, cull, L.hist, L.nbtot, kred, key16); \
+        hipLaunchKernelGGL(k_seg_rowscan, rgrid, blk, 0, L.st, L.hist, L.nbtot, (const DvsSeg*)seg_in, L.V, adaptive, bits, (uint32_t)(FE_BLOCK * I), L.totals); \
+        hipLaunchKernelGGL((k_seg_scatter<I, A>), grid, blk, 0, L.st, kin, vin, kout, vout, (const DvsSeg*)seg_in, seg_out, L.V, adaptive, pass, shift, bits, \
+                           cull, key_add_per_view, (const uint32_t*)L.hist, L.nbtot, (const uint32_t*)L.totals, key16, ranges_enc);               \
+    } while (0)
+    if (L.items == 8) { if (L.rank_atomic) FE_PASS(8, true); else FE_PASS(8, false); }
+    else { if (L.rank_atomic) FE_PASS(16, true); else FE_PASS(16, false); }
+#undef FE_PASS
     return hipGetLastError();
 }
 
 // A5, low 32 key bits: every view's depth keys (keys0, view-major [V][n], culled = 0xFFFFFFFF) -> the visible splats' indices in
 // depth order in vals1[view * n + j], j < seg_vis[view].count. Three passes: keys0 -> (keys1, vals1) -> (keys0, vals0) -> vals1.
 hipError_t dvs_launch_depth_sort(hipStream_t st, int n, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
-                                 DvsSeg* seg_all, DvsSeg* seg_vis, const uint32_t* kred, uint32_t* hist, uint32_t* totals) {
+                                 DvsSeg* seg_all, DvsSeg* seg_vis, const uint32_t* kred, uint32_t* hist, uint32_t* totals, int rank_atomic) {
     if (n <= 0 || V <= 0) return hipSuccess;
     FeSortLaunch L;
-    L.st = st; L.V = V; L.items = fe_items_for((uint64_t)n * V);
+    L.st = st; L.V = V; L.items = fe_items_for((uint64_t)n * V); L.rank_atomic = rank_atomic;
     const uint32_t part = (uint32_t)FE_BLOCK * L.items;
     L.grid_per_view = ((uint32_t)n + part - 1) / part;
     L.hist = hist; L.nbtot = L.grid_per_view * (uint32_t)V + 1; L.totals = totals;
@@ -449,13 +469,13 @@ uint32_t dvs_fe_part_for(uint64_t grid_elems) { return (uint32_t)FE_BLOCK * (uin
 
 hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, DvsSeg* seg, int bit_lo, int bits,
                                uint64_t grid_elems, uint32_t part, uint32_t nbtot, uint32_t* hist, uint32_t* totals, uint32_t key_add_per_view,
-                               int* result_in, uint32_t* ranges_enc, int write_last_keys, int first_keys16) {
+                               int* result_in, uint32_t* ranges_enc, int write_last_keys, int first_keys16, int rank_atomic) {
     if (result_in) *result_in = 0;
     if (V <= 0 || bits <= 0) return hipSuccess;
     int npass, widths[4];
     fe_split_bits(bits, &npass, widths);
     FeSortLaunch L;
-    L.st = st; L.V = V; L.items = (int)(part / FE_BLOCK);
+    L.st = st; L.V = V; L.items = (int)(part / FE_BLOCK); L.rank_atomic = rank_atomic;
     uint64_t per_view = (grid_elems + (uint64_t)V - 1) / (uint64_t)V;
     uint64_t g = (per_view + part - 1) / part + 1;
     if (g > 65535u * 16u) g = 65535u * 16u;
@@ -475,6 +495,63 @@ hipError_t dvs_launch_seg_sort(hipStream_t st, int V, uint32_t* keys0, uint32_t*
     }
     if (result_in) *result_in = c;
     return hipSuccess;
+}
+
+// ---- is the returning LDS add lane-ordered on this device? ---------------------------------------------------------------------------
+// Every wave of the launch ranks 64 x ROUNDS synthetic digits per pattern both ways — the ballot multisplit with leader-written counters
+// (the form rounds 2-5 shipped, correct by construction) and ds_add_rtn_u32 on packed u16 counters exactly as k_seg_scatter<.., true>
+// does — and raises *bad on the first disagreement. Patterns: one digit for all lanes (64-way conflict), two digits sharing a counter
+// word, digits by lane pairs / triples / halves, stripes, and hashed digits of 1 .. 9 bits, with the four waves of a workgroup hammering
+// their own counters at the same time as in the scatter. 0 disagreements over ~10^6 ranks -> the atomic ranking is selected.
+__global__ void __launch_bounds__(FE_BLOCK)
+k_fe_probe_rank_atomic(uint32_t* __restrict__ bad, uint32_t seed) {
+    __shared__ uint32_t cnt_a[FE_WAVES * 256];             // packed u16 counters, atomic form: 512 digits per wave
+    __shared__ uint16_t cnt_b[FE_WAVES * 512];             // ballot form
+    const uint32_t lane = fe_lane(), wave = threadIdx.x >> 6;
+    uint32_t errs = 0;
+    for (uint32_t pat = 0; pat < 24; ++pat) {
+        for (uint32_t e = threadIdx.x; e < FE_WAVES * 256; e += FE_BLOCK) cnt_a[e] = 0u;
+        for (uint32_t e = threadIdx.x; e < FE_WAVES * 512; e += FE_BLOCK) cnt_b[e] = 0;
+        __syncthreads();
+        const uint32_t bits = pat < 8 ? 9u : 1u + (pat - 8u) % 9u;
+        for (uint32_t r = 0; r < 16; ++r) {
+            uint32_t h = (lane * 0x9E3779B1u) ^ ((blockIdx.x * FE_WAVES + wave) * 0x85EBCA6Bu) ^ ((pat * 16u + r) * 0xC2B2AE35u) ^ seed;
+            h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+            uint32_t d;
+            switch (pat) {
+                case 0: d = 5u; break;                                   // every lane the same counter
+                case 1: d = 6u + (lane & 1u); break;                     // the two halves of one word, alternating
+                case 2: d = lane >> 1; break;                            // pairs
+                case 3: d = lane / 3u; break;
+                case 4: d = lane >> 5; break;                            // the two wave halves
+                case 5: d = lane & 7u; break;                            // stripes
+                case 6: d = (lane & 1u) ? 511u : (h & 3u); break;
+                case 7: d = 63u - lane; break;                           // no conflicts, descending
+                default: d = h & ((1u << bits) - 1u); break;
+            }
+            const bool valid = (h >> 20 & 15u) != 0u || pat < 8;         // a few idle lanes in the hashed patterns
+            uint32_t ra = 0, rb = 0;
+            if (valid) {
+                const uint32_t old = atomicAdd(&cnt_a[wave * 256u + (d >> 1)], (d & 1u) ? 0x10000u : 1u);
+                ra = (d & 1u) ? (old >> 16) : (old & 0xFFFFu);
+            }
+            const uint64_t peers = fe_match(d, valid, 9u);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            if (valid) {
+                const uint32_t prev = cnt_b[wave * 512u + d];
+                if (below == 0) cnt_b[wave * 512u + d] = (uint16_t)(prev + (uint32_t)__popcll(peers));
+                rb = prev + below;
+            }
+            errs += (valid && ra != rb) ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (errs) atomicAdd(bad, errs);
+}
+hipError_t dvs_fe_probe_rank_atomic(hipStream_t st, uint32_t* bad_dev /*one zeroed word*/) {
+    hipLaunchKernelGGL(k_fe_probe_rank_atomic, dim3(512), dim3(FE_BLOCK), 0, st, bad_dev, 0x1234567u);
+    hipLaunchKernelGGL(k_fe_probe_rank_atomic, dim3(512), dim3(FE_BLOCK), 0, st, bad_dev, 0x89ABCDEu);
+    return hipGetLastError();
 }
 
 // ---- tile rectangles: three record formats -----------------------------------------------------------------------------------------

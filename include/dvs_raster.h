@@ -258,6 +258,10 @@ int dvs_get_num_rendered(dvs_ctx* ctx, void* stream, uint64_t* num_rendered);
  * enlarged since dvs_create, the T of the last forward the host knows (synchronous forward: that forward's; asynchronous: an earlier
  * one's) and how many forwards overflowed it (each of those was reported once as DVS_ERR_CAPACITY). Any pointer may be NULL. */
 int dvs_get_arena_info(dvs_ctx* ctx, uint64_t* instance_capacity, uint64_t* grow_events, uint64_t* last_num_rendered, uint64_t* overflows);
+/* How the radix sorts of the context rank keys inside a wavefront: 1 = returning LDS adds (selected at dvs_create when the device serves
+ * the lanes that add to one LDS address in lane order — probed on the device, csrc/frontend.hip), 0 = ballot multisplit (the fallback,
+ * and what DVS_FE_RANK=ballot forces). Both give the same stable order; the parity suite runs both. -1 for a NULL context. */
+int dvs_get_sort_rank_mode(dvs_ctx* ctx);
 
 /* TEST HOOK of the parity suite. While take_masks is non-NULL, every single-view synchronous forward on the context (default A7 kernel)
  * also records ITS OWN threshold decisions: take_masks[4 * j + q] (device memory, 8-byte aligned, capacity_instances * 4 words, zeroed by

@@ -621,6 +621,57 @@ def test_sort_pairs(rast):
         np.testing.assert_array_equal(v_d.cpu().numpy().view(np.uint32), vals[order])
 
 
+def test_sort_rank_modes_agree(gpu_device):
+    """Round 6: the scatters of both radix sorts rank inside a wave by returning LDS adds when the device serves the lanes of one LDS
+    address in lane order (probed on the device at dvs_create: dvs_get_sort_rank_mode == 1), else by the ballot multisplit of rounds
+    2-5 (DVS_FE_RANK=ballot forces it). Both must give THE stable order: pair sorts on adversarial digit distributions (all keys equal,
+    two keys alternating, long runs, few distinct keys, random with many duplicates; 8- and 16-keys-per-thread partitions) against
+    numpy's stable argsort in both modes, and a 3-view forward whose lists, ranges, n_contrib and images are bit-identical between them."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    from divshot_amd import lib
+    rng = np.random.default_rng(23)
+    cases = []
+    for n in (4096 * 3 + 17, 1_600_000):                      # ITEMS = 8 and ITEMS = 16 partitions
+        cases += [np.full(n, 0x1234567, np.uint32), (np.arange(n) & 1).astype(np.uint32) * 0x10001,
+                  (np.arange(n) // 1000).astype(np.uint32), rng.integers(0, 5, n).astype(np.uint32) * 0x01010101,
+                  rng.integers(0, 2**13, n).astype(np.uint32), rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)]
+    n, W, H, V = 6007, 208, 120, 3
+    spec = dv.make_spec(n, W, H, sh_degree=2, n_cams=4, seed=17)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, i + 1) for i in range(V)]
+    got = {}
+    old = os.environ.get("DVS_FE_RANK")
+    try:
+        for mode in ("ballot", "default"):
+            if mode == "ballot": os.environ["DVS_FE_RANK"] = "ballot"
+            else: os.environ.pop("DVS_FE_RANK", None)
+            r = Rasterizer(0, max_splats=max(n, 1 << 16), max_w=W, max_h=H, max_views=V)
+            rm = lib.dvs_get_sort_rank_mode(r.ctx)
+            assert rm == (0 if mode == "ballot" else 1), (mode, rm)      # an MI355X passes the probe: the default IS the atomic ranking
+            for keys in cases:
+                vals = np.arange(keys.size, dtype=np.uint32)
+                k_d = torch.from_numpy(keys.view(np.int32).copy()).to(r.tdev)
+                v_d = torch.from_numpy(vals.view(np.int32).copy()).to(r.tdev)
+                r.sort_pairs(k_d, v_d, 0, 32)
+                torch.cuda.synchronize()
+                order = np.argsort(keys, kind="stable")
+                np.testing.assert_array_equal(v_d.cpu().numpy().view(np.uint32), vals[order], err_msg=mode)
+                np.testing.assert_array_equal(k_d.cpu().numpy().view(np.uint32), keys[order], err_msg=mode)
+            Pd = params_to_device(P, r.tdev)
+            imgs = r.forward_views(Pd, cams, sh_degree=2)
+            torch.cuda.synchronize()
+            got[mode] = (imgs.clone(), [r.view_saved(v) for v in range(V)])
+            r.close()
+    finally:
+        if old is None: os.environ.pop("DVS_FE_RANK", None)
+        else: os.environ["DVS_FE_RANK"] = old
+    assert torch.equal(got["ballot"][0], got["default"][0])
+    for v in range(V):
+        for k in ("vals", "sorted_tile", "ranges", "n_contrib", "radii"):
+            np.testing.assert_array_equal(got["ballot"][1][v][k], got["default"][1][v][k], err_msg=f"view {v} {k}")
+
+
 def test_error_paths_and_nan_inputs(gpu_device):
     """Status codes instead of crashes or silent fallbacks; NaN / inf parameters cull the splat and poison nothing else."""
     import ctypes as C
