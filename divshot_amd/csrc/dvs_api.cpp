@@ -536,13 +536,19 @@ static int bwd_project(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dv
         DvsCams dcams;
         float campos[DVS_MAX_VIEWS * 3];
         for (int v = 0; v < V; ++v) { dcams.c[v] = to_dev_cam(cams[v]); for (int k = 0; k < 3; ++k) campos[3 * v + k] = cams[v].campos[k]; }
+        // Nobody asked for the per-view colour gradients (one GPU, or the plain all-reduce exchange): the kernel builds the SH rows in its
+        // epilogue (k_preprocess_bwd_views<.., FUSE_SH>). With out->dcolor (the factorised exchange, dvs_raster_backward_dcolor's twin) it
+        // emits them and dvs_launch_sh_grad_combine builds the rows — here right away if sh0 / shN are given too, else after the all-gather.
+        const char* nf = getenv("DVS_A9_NO_FUSE_SH");                      // cross-check switch (tests; read per call so that one process can run both)
+        const bool no_fuse = nf && nf[0] == '1';
+        const bool fuse = !out->dcolor && out->sh0 && out->shN && !no_fuse;
         float* dcol = out->dcolor;
-        if (!dcol) { int r = c->dcolor.ensure((size_t)V * n * 3 * sizeof(float)); if (r != DVS_OK) return r; dcol = c->dcolor.as<float>(); }
+        if (!dcol && !fuse) { int r = c->dcolor.ensure((size_t)V * n * 3 * sizeof(float)); if (r != DVS_OK) return r; dcol = c->dcolor.as<float>(); }
         HIPCHECK(dvs_launch_preprocess_bwd_views(st, n, V, p->pos, p->shN, p->opacity, p->scale, p->rot, dcams, opts->sh_degree,
                                                  opts->antialias, s.radii, s.flags, c->g_rows.as<float>(), out->pos, out->opacity, out->scale,
                                                  out->rot, opts->absgrad ? out->absgrad2d : nullptr, out->mean2d, dcol, opts->accumulate,
-                                                 c->keep_rows ? 0 : 1, opts->grad_mode));
-        if (out->sh0 && out->shN)          // (NULL: the factorised exchange builds them after its all-gather of dcolor)
+                                                 c->keep_rows ? 0 : 1, opts->grad_mode, 0, -1, fuse ? out->sh0 : nullptr, fuse ? out->shN : nullptr));
+        if (!fuse && out->sh0 && out->shN)          // (NULL: the factorised exchange builds them after its all-gather of dcolor)
             HIPCHECK(dvs_launch_sh_grad_combine(st, n, p->pos, opts->sh_degree, V, campos, dcol, out->sh0, out->shN, opts->accumulate, 1));
     } else {
         for (int v = 0; v < V; ++v) {

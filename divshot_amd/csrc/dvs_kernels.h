@@ -26,7 +26,9 @@ hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, c
                                            const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos, float* g_opacity,
                                            float* g_scale, float* g_rot, float* out_absgrad2d, float* out_mean2d, float* out_dcolor,
                                            int accumulate, int rezero_rows, int grad_mode, int first = 0, int count = -1 /*splat range of this
-                                           launch: [first, first + count), count < 0 = up to n*/);
+                                           launch: [first, first + count), count < 0 = up to n*/,
+                                           float* g_sh0 = nullptr, float* g_shN = nullptr /*both given: the kernel builds the SH rows itself
+                                           (tiled layout) from the views' colour gradients and does NOT write out_dcolor — the one-GPU path*/);
 // g_sh0 / g_shN may be nullptr in dvs_launch_preprocess_bwd (factorised exchange); this rebuilds them from dcolor[n_views,n,3].
 hipError_t dvs_launch_sh_grad_combine(hipStream_t st, int n, const float* pos, int deg, int n_views, const float* campos_host,
                                       const float* dcolor, float* g_sh0, float* g_shN, int accumulate, int shn_tiled);

@@ -395,7 +395,8 @@ k_seg_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__
 }
 
 static inline int fe_items_for(uint64_t n_total) {
-    return n_total <= 1500000ull ? 8 : 16;
+    static const uint64_t thr = [] { const char* e = getenv("DVS_FE_ITEMS8_BELOW"); return e ? (uint64_t)atoll(e) : 1500000ull; }();
+    return n_total <= thr ? 8 : 16;
 }
 
 size_t dvs_fe_hist_words(uint64_t max_elems, int n_views, int max_bins) {

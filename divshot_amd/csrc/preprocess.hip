@@ -687,7 +687,7 @@ k_preprocess_bwd(int n, const float* __restrict__ pos, const float* __restrict__
 // splat and view) and k_sh_grad_combine builds sh0 / shN from it afterwards — on one GPU right away, in data-parallel runs after the
 // all-gather of dcolor (the factorised exchange), with the same kernel. Per view the same expressions in the same order as
 // k_preprocess_bwd, so the geometry gradients of a batch are bit-identical to its views run one by one with opts.accumulate.
-template <bool ACCUM, bool NOHOIST>
+template <bool ACCUM, bool NOHOIST, bool FUSE_SH /*build the SH rows here instead of emitting per-view colour gradients (below)*/>
 __global__ void __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read through dvs_load_cam() */, int n_views, int n,
                        const float* __restrict__ pos, const float* __restrict__ shN, const float* __restrict__ opacity,
@@ -695,11 +695,13 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
                        const int* __restrict__ radii /*[V,n]*/, const uint32_t* __restrict__ flags /*[V,n]*/,
                        float4* __restrict__ grad_rows /*[V,n,3]: A8 moments; re-zeroed here*/,
                        float* __restrict__ g_pos, float* __restrict__ g_opacity, float* __restrict__ g_scale, float* __restrict__ g_rot,
-                       float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor /*[V,n,3]*/,
+                       float2* __restrict__ out_absgrad2d, float2* __restrict__ out_mean2d, float* __restrict__ out_dcolor /*[V,n,3]; FUSE_SH: unused*/,
+                       float* __restrict__ g_sh0 /*FUSE_SH: [n,3]*/, float* __restrict__ g_shN /*FUSE_SH: tiled rows*/,
                        int rezero, int grad_mode, int i0 /*this launch covers the splats [i0, i1): all of them, or one chunk of a*/,
                        int i1 /*data-parallel step that sends each chunk's gradients off while the next chunk computes*/) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*6]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*6] (+ FUSE_SH: [n_views][6][PP_BLOCK] colour gradient | unit direction)
     (void)cams_arg;
+    float* const l_view = lds + PP_BLOCK * 6;
     const int64_t base = (int64_t)i0 + (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
     const bool valid = i < i1;
@@ -790,6 +792,10 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
                     }
                 }
             }
+            if (FUSE_SH) {              // the epilogue builds the SH rows from these: what k_sh_grad_combine would re-read and recompute
+                float* lv = l_view + (size_t)view * (6 * PP_BLOCK) + threadIdx.x;
+                lv[0] = gc[0]; lv[PP_BLOCK] = gc[1]; lv[2 * PP_BLOCK] = gc[2]; lv[3 * PP_BLOCK] = ux; lv[4 * PP_BLOCK] = uy; lv[5 * PP_BLOCK] = uz;
+            }
             {
                 a9_dir_grad(deg, ux, uy, uz, sk, gdir);
                 const float ug = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
@@ -804,13 +810,47 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
         // per-view colour gradient, always overwritten (zero for culled splats and clamped channels). Stored straight from the lane
         // (three 4-B stores at stride 12; the L2 merges them): staging it through LDS for full-line stores cost two workgroup barriers
         // per view, which this latency-bound kernel feels more than the partial-line writes
-        if (valid) {
+        if (!FUSE_SH && valid) {
             float* dc = out_dcolor + ((size_t)view * n + (size_t)i) * 3;
             dc[0] = gcol[0]; dc[1] = gcol[1]; dc[2] = gcol[2];
         }
     }
 
     if (vis) a9_sigma_to_params(in_s0, in_s1, in_s2, in_q, Gs, gsc, gq);       // once per splat: linear in the summed dL/dSigma
+    // FUSE_SH (round 6; the one-GPU path, where nobody else needs the per-view colour gradients): dL/dsh0 = sum_v SH_C0 gc_v and
+    // dL/dshN[k] = sum_v basis_k(dir_v) gc_v are built HERE, after the view loop — its registers are free by now — from the (gc, dir)
+    // pairs the loop left in LDS, with the expressions and the view order of k_sh_grad_combine (bit-identical rows). Saved against the
+    // two-kernel form: 12 B per (view, splat) written and read back, the positions read again, a launch.
+    float acc0[3] = {0.f, 0.f, 0.f};
+    if (FUSE_SH) {
+        float acc[48];
+#pragma unroll
+        for (int e = 0; e < 48; ++e) acc[e] = 0.f;
+        for (int view = 0; view < n_views; ++view) {
+            if (!((vis >> view) & 1u)) continue;
+            const float* lv = l_view + (size_t)view * (6 * PP_BLOCK) + threadIdx.x;
+            const float gc[3] = {lv[0], lv[PP_BLOCK], lv[2 * PP_BLOCK]};
+            if (gc[0] == 0.f && gc[1] == 0.f && gc[2] == 0.f) continue;              // fully clamped in this view
+            float bas[16];
+            dvs_sh_basis(deg, lv[3 * PP_BLOCK], lv[4 * PP_BLOCK], lv[5 * PP_BLOCK], bas);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) acc0[ch] = __builtin_fmaf(bas[0], gc[ch], acc0[ch]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) acc[(k - 1) * 3 + ch] = __builtin_fmaf(bas[k], gc[ch], acc[(k - 1) * 3 + ch]);
+        }
+        if (valid) {
+            float4* d4 = reinterpret_cast<float4*>(g_shN);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                float4 o = c == 11 ? make_float4(acc[44], 0.f, 0.f, 0.f) : make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
+                const int64_t idx = shn_tiled_f4(i, c);
+                if (ACCUM) { const float4 p = d4[idx]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                d4[idx] = o;
+            }
+        }
+    }
     if (valid) {
         if (out_absgrad2d) {
             float2 a = ag;
@@ -839,6 +879,13 @@ k_preprocess_bwd_views(DvsCams cams_arg /* MUST stay the first parameter: read t
     __syncthreads();
     stage_rows_out<3, ACCUM>(g_pos, l_pos, base, i1);
     stage_rows_out<3, ACCUM>(g_scale, l_scl, base, i1);
+    if (FUSE_SH) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l_pos[threadIdx.x * 3 + k] = acc0[k];
+        __syncthreads();
+        stage_rows_out<3, ACCUM>(g_sh0, l_pos, base, i1);
+    }
 }
 
 // ---- factorised SH gradient: rows from per-view colour gradients -----------------------------------------------------
@@ -1016,22 +1063,23 @@ hipError_t dvs_launch_preprocess_bwd_views(hipStream_t st, int n, int n_views, c
                                            const float* scale, const float* rot, const DvsCams& cams, int deg, int antialias,
                                            const int* radii, const uint32_t* flags, float* grad_rows, float* g_pos, float* g_opacity,
                                            float* g_scale, float* g_rot, float* out_absgrad2d, float* out_mean2d, float* out_dcolor,
-                                           int accumulate, int rezero, int grad_mode, int first, int count) {
+                                           int accumulate, int rezero, int grad_mode, int first, int count, float* g_sh0, float* g_shN) {
     if (n <= 0 || n_views <= 0) return hipSuccess;
     const int i0 = first < 0 ? 0 : first, i1 = count < 0 ? n : (first + count < n ? first + count : n);
     if (i1 <= i0) return hipSuccess;
     const int grid = (i1 - i0 + PP_BLOCK - 1) / PP_BLOCK;
-    const size_t lds = (size_t)PP_BLOCK * 6 * sizeof(float);
+    const bool fuse = g_sh0 && g_shN;               // the SH rows are built in the kernel's epilogue; out_dcolor is not written
+    const size_t lds = (size_t)PP_BLOCK * (6 + (fuse ? 6 * n_views : 0)) * sizeof(float);
 #ifdef DVS_EXPERIMENT
     static const bool nohoist = getenv("DVS_A9V_NOHOIST") && getenv("DVS_A9V_NOHOIST")[0] == '1';      // experiment builds only
 #else
     constexpr bool nohoist = false;
 #endif
-#define DVS_PPV1(A, N)                                                                                                          \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<A, N>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
+#define DVS_PPV1(A, N, F)                                                                                                        \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<A, N, F>), dim3(grid), dim3(PP_BLOCK), lds, st, cams, n_views, n, pos, shN, opacity, scale, rot, \
                        deg, antialias, radii, flags, (float4*)grad_rows, g_pos, g_opacity, g_scale, g_rot,                         \
-                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, rezero, grad_mode, i0, i1)
-#define DVS_PPV(A) do { if (nohoist) DVS_PPV1(A, true); else DVS_PPV1(A, false); } while (0)
+                       (float2*)out_absgrad2d, (float2*)out_mean2d, out_dcolor, g_sh0, g_shN, rezero, grad_mode, i0, i1)
+#define DVS_PPV(A) do { if (fuse) DVS_PPV1(A, false, true); else if (nohoist) DVS_PPV1(A, true, false); else DVS_PPV1(A, false, false); } while (0)
     if (accumulate) DVS_PPV(true); else DVS_PPV(false);
 #undef DVS_PPV
 #undef DVS_PPV1

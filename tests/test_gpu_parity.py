@@ -896,6 +896,50 @@ def test_multi_view_batch_equals_single_views(gpu_device, tiled, bwd):
     single.close(); batch.close()
 
 
+def test_fused_sh_rows_equal_the_two_kernel_form(gpu_device):
+    """Round 6: on one GPU the multi-view A9 builds the SH rows in its epilogue (k_preprocess_bwd_views<.., FUSE_SH>: colour gradient and
+    unit direction of every view parked in LDS) instead of writing per-view colour gradients for k_sh_grad_combine. Same expressions, same
+    view order: sh0 / shN rows BIT-identical to the two-kernel form (DVS_A9_NO_FUSE_SH=1), every other group too; overwrite and
+    accumulate; 1, 3 and 8 views; degree 0, 2, 3; a view that sees nothing."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    n, W, H = 5003, 208, 120
+    for V, deg in ((1, 3), (3, 2), (8, 3), (2, 0)):
+        spec = dv.make_spec(n, W, H, sh_degree=deg, n_cams=V + 1, seed=41 + V)
+        P = dv.synth_splats(spec)
+        cams = [dv.synth_camera(spec, i + 1) for i in range(V)]
+        if V == 3:                                                   # the middle camera looks the other way: it sees nothing
+            for c_ in range(4):
+                cams[1].view[c_ * 4 + 2] = -cams[1].view[c_ * 4 + 2]     # depth axis flipped: everything is behind this camera
+        r = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+        r.keep_intermediates(True)
+        Pd = params_to_device(P, r.tdev)
+        Pd["shN"] = r.shn_relayout(Pd["shN"], n, to_tiled=True)
+        imgs = r.forward_views(Pd, cams, sh_degree=deg, absgrad=True, shn_tiled=True)
+        dL = torch.rand(imgs.shape, device=r.tdev, generator=torch.Generator(device=r.tdev).manual_seed(3)) - 0.5
+        r.backward_composite(dL.contiguous())
+        out = {}
+        old = os.environ.get("DVS_A9_NO_FUSE_SH")
+        try:
+            for tag in ("two", "fused"):
+                if tag == "two": os.environ["DVS_A9_NO_FUSE_SH"] = "1"
+                else: os.environ.pop("DVS_A9_NO_FUSE_SH", None)
+                g = r.backward_project()
+                g = {k: t.clone() for k, t in g.items()}
+                g2 = r.backward_project(grads={k: t.clone() for k, t in g.items()}, accumulate=True)
+                torch.cuda.synchronize()
+                out[tag] = (g, {k: t.clone() for k, t in g2.items()})
+        finally:
+            if old is None: os.environ.pop("DVS_A9_NO_FUSE_SH", None)
+            else: os.environ["DVS_A9_NO_FUSE_SH"] = old
+        for k in KEYS:
+            assert torch.equal(out["two"][0][k], out["fused"][0][k]), (V, deg, k)
+            assert torch.equal(out["two"][1][k], out["fused"][1][k]), (V, deg, k, "accumulate")
+        assert out["fused"][0]["sh0"].abs().max() > 0 and (deg == 0 or out["fused"][0]["shN"].abs().max() > 0)
+        assert torch.allclose(out["fused"][1]["shN"], 2 * out["fused"][0]["shN"], rtol=1e-6, atol=0)
+        r.close()
+
+
 def test_live_lists_give_the_same_gradients(gpu_device):
     """dvs_set_live_lists: the "tr" backward over the forward's compacted lists (entries that reach their tile) against the same
     kernel over the full lists — one view and a 3-view pass, a scene with many entries that miss their tiles (small, faint splats) and
