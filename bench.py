@@ -86,6 +86,26 @@ def read_clocks(dev_index=0):
     return out
 
 
+def kernel_source_sha():
+    """sha256 (16 hex digits) over divshot_amd/csrc/*.{hip,h,cpp} — the same digest tools/make_traffic_json.py stores in profiles/r*_traffic.json, so
+    that the line can say whether the committed PMC counters were collected on the kernels it is timing (stale counters silently
+    divided by fresh times)."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "divshot_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters_provenance(tfile, tj):
+    cur = kernel_source_sha()
+    return {"file": "profiles/" + os.path.basename(tfile), "kernel_source_sha16": tj.get("kernel_source_sha16"), "current_kernel_source_sha16": cur,
+            "collected_on_these_kernels": tj.get("kernel_source_sha16") == cur,
+            "note": "counter bytes come from separate rocprofv3 --pmc passes committed under profiles/; when collected_on_these_kernels is false they "
+                    "describe an earlier build and every *_by_counters figure mixes them with this run's times"}
+
+
 def cpu_baseline(workload, max_seconds=60.0):
     """The CPU oracle (kind 'port': the reference's CPU libtorch path is not in its tree)
     timed on this box's host cores: one fwd+bwd view of the bench workload, all cores (OpenMP)."""
@@ -689,7 +709,7 @@ def main():
             kern = "k_" + dom
             if dom == "render_bwd":
                 kern = {"blocks": "k_render_bwd_blocks<", "reduce": "k_render_bwd<", "mm": "k_render_bwd_mm<", "tr": "k_render_bwd_tr<"}[args.bwd_variant]
-            traffic, traffic_src, same_run, counter_bytes_step = None, None, False, None
+            traffic, traffic_src, same_run, counter_bytes_step, counters_prov = None, None, False, None, None
             try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs)
                 import glob
                 tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]      # the latest round's PMC passes
@@ -702,6 +722,7 @@ def main():
                     if same_run and kname.startswith(kern):
                         traffic = rec_["hbm_bytes_per_launch_corrected"]
                         traffic_src = "profiles/" + os.path.basename(tfile) + " (2*FETCH_SIZE + WRITE_SIZE, KB->B)"
+                counters_prov = counters_provenance(tfile, tj)
             except Exception:
                 pass
             # VALU issue occupancy of the same kernel from the committed SQ counter pass (its own rocprofv3 run): SQ_ACTIVE_INST_VALU
@@ -746,7 +767,7 @@ def main():
             except Exception:
                 pass
             roofline = {"bound": "hbm", "kernel": kern.rstrip("<"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "counters": counters_prov,
                         "algorithmic_bytes_per_launch": ab[dom] * views_per_launch, "views_per_launch": views_per_launch, "avg_launch_ms": dur_ms,
                         "avg_launch_ms_isolated": single[dom], "avg_launch_source": ("hipEvent pairs around the kernel inside a replica of the timed "
                         "region (dvs_enable_kernel_probe)" if in_step_ms else "per-stage hipEvent timing, one view at a time"), "valu_issue": valu,

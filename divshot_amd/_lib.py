@@ -94,6 +94,8 @@ _PROTOS = {
     "dvs_set_async": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_get_num_rendered": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "dvs_get_sort_rank_mode": (C.c_int, [C.c_void_p]),
+    "dvs_debug_sort_depth_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "dvs_set_export_sorted_tiles": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_get_arena_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "dvs_set_backward_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dvs_debug_record_decisions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

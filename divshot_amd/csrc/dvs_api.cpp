@@ -80,6 +80,7 @@ struct dvs_ctx {
     uint32_t* live_pos = nullptr;
     bool live_lists = true;              // env DVS_LIVE_LISTS=0: A8 walks the full lists (A/B and parity of the two routes)
     Buf tmp_keys, tmp_vals;
+    bool export_tiles = false;           // dvs_set_export_sorted_tiles: asynchronous forwards materialise the sorted tile ids too
     int fe_rank_atomic = 0;              // the sorts' scatters rank by returning LDS adds (frontend.hip): the device passed dvs_fe_probe_rank_atomic
     Buf ranges_canon;                    // (start, end) per tile as k_render_fwd decodes them when A6 rides on the tile sort (frontend.hip)
     Buf ranges, final_T, n_contrib;      // `ranges` starts with the front end's zeroed words (fe_zero_bytes), the tile ranges follow: ONE memset per forward
@@ -388,7 +389,7 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
         // the ranges). An asynchronous forward does not even write the sorted tile ids: nothing on the device reads them, and
         // dvs_fwd_state.sorted_tile is then NULL (dvs_raster.h).
         const bool fuse_a6 = (c->fwd_variant == DVS_FWD_QUADRANT || V > 1) && !fe_no_fuse();
-        const bool write_keys = !(fuse_a6 && c->async_T);
+        const bool write_keys = !(fuse_a6 && c->async_T) || c->export_tiles;
         if (n > 0) {
             const uint64_t cap = c->async_T ? c->inst_cap : T;
             const uint32_t nbtot = (uint32_t)(cap / tile_part) + (uint32_t)V + 2u;
@@ -594,6 +595,7 @@ static int backward_views(dvs_ctx* c, void* stream, const dvs_splats* p, const d
                           const float* dL_drgb, const dvs_splat_grads* out, const char* who) {
     int r;
     if (!dL_drgb) { g_last_error = "dvs_raster_backward: null argument"; return DVS_ERR_INVALID; }
+    if ((uintptr_t)dL_drgb & 15u) { g_last_error = "dvs_raster_backward: dL_drgb must be 16-byte aligned (the composite backward reads it as 16-byte words)"; return DVS_ERR_INVALID; }
     if ((r = check_grads(p, out, who)) != DVS_OK) return r;
     if ((r = check_bwd_args(c, p, cams, V, opts, who)) != DVS_OK) return r;
     HIPCHECK(hipSetDevice(c->device));
@@ -617,6 +619,7 @@ int dvs_raster_backward_views(dvs_ctx* c, void* stream, const dvs_splats* p, con
 int dvs_raster_backward_composite(dvs_ctx* c, void* stream, const dvs_camera* cam, const dvs_opts* opts, const float* dL_drgb) {
     int r;
     if (!dL_drgb) { g_last_error = "dvs_raster_backward_composite: null argument"; return DVS_ERR_INVALID; }
+    if ((uintptr_t)dL_drgb & 15u) { g_last_error = "dvs_raster_backward_composite: dL_drgb must be 16-byte aligned (the composite backward reads it as 16-byte words)"; return DVS_ERR_INVALID; }
     if (!c) { g_last_error = "dvs_raster_backward_composite: null argument"; return DVS_ERR_INVALID; }
     if ((r = check_bwd_args(c, nullptr, cam, c->n_views, opts, "dvs_raster_backward_composite")) != DVS_OK) return r;
     HIPCHECK(hipSetDevice(c->device));
@@ -692,7 +695,8 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
     uint32_t* v[2] = {vals, c->tmp_vals.as<uint32_t>()};
     int cur = 0;
     {
-        if (n >= (1ull << 32)) { g_last_error = "dvs_sort_pairs_u32: n must be below 2^32"; return DVS_ERR_CAPACITY; }
+        // (partition offsets are 32-bit: the last partition's element indices must not wrap — ADVICE r05)
+        if (n > (1ull << 32) - 4097ull) { g_last_error = "dvs_sort_pairs_u32: n must be at most 2^32 - 4097"; return DVS_ERR_CAPACITY; }
         if ((r = c->fe_hist.ensure(dvs_fe_hist_words(n, 1, 512) * 4)) != DVS_OK) return r;
         const uint32_t part = dvs_fe_part_for(n);
         HIPCHECK(dvs_launch_seg_init(st, (int)n, 1, 0, fe_seg_all(c)));      // one segment: [0, n)
@@ -704,6 +708,39 @@ int dvs_sort_pairs_u32(dvs_ctx* c, void* stream, uint32_t* keys, uint32_t* vals,
         HIPCHECK(hipMemcpyAsync(keys, k[1], n * 4, hipMemcpyDeviceToDevice, st));
         HIPCHECK(hipMemcpyAsync(vals, v[1], n * 4, hipMemcpyDeviceToDevice, st));
     }
+    return DVS_OK;
+}
+
+// TEST HOOK (dvs_raster.h): the forward's range-adaptive depth sort (A5, low 32 key bits) on caller-supplied keys, one view.
+int dvs_debug_sort_depth_keys(dvs_ctx* c, void* stream, const uint32_t* keys, uint64_t n, uint32_t* sorted_ids, uint32_t* n_sorted, uint32_t* digit_bits) {
+    if (!c || !keys || !sorted_ids || !n_sorted || n == 0 || n > c->max_splats * (uint64_t)c->max_views || n >= (1ull << 31)) {
+        g_last_error = "dvs_debug_sort_depth_keys: bad argument (n must be in [1, max_splats * max_views])"; return DVS_ERR_INVALID;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    // the key range a forward's A2 would have left in the view's 64 slots: here reduced on the host from a copy of the keys
+    std::vector<uint32_t> h(n);
+    HIPCHECK(hipMemcpyAsync(h.data(), keys, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u; bool any = false;
+    for (uint32_t k : h) if (k != 0xFFFFFFFFu) { mn = k < mn ? k : mn; mx = k > mx ? k : mx; any = true; }
+    uint32_t slots[64 * 16] = {0};
+    if (any) { slots[0] = ~mn; slots[1] = mx; }
+    HIPCHECK(hipMemcpyAsync(fe_kred(c), slots, sizeof slots, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(c->key[0].p, keys, n * 4, hipMemcpyDeviceToDevice, st));
+    const uint32_t rows = dvs_depth_sort_rows_per_view((int)n, 1);
+    HIPCHECK(dvs_launch_seg_init(st, (int)n, 1, rows, fe_seg_all(c)));
+    c->fe_seg_n = -1;                                                       // (the forward's descriptors are gone)
+    HIPCHECK(dvs_launch_depth_sort(st, (int)n, 1, c->key[0].as<uint32_t>(), c->ids[0].as<uint32_t>(), c->key[1].as<uint32_t>(), c->ids[1].as<uint32_t>(),
+                                   fe_seg_all(c), fe_seg_vis(c), fe_kred(c), c->fe_hist.as<uint32_t>(), fe_totals(c), c->fe_rank_atomic));
+    DvsSeg sv;
+    HIPCHECK(hipMemcpyAsync(&sv, fe_seg_vis(c), sizeof sv, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    *n_sorted = sv.count;
+    if (digit_bits) *digit_bits = sv.bits;
+    HIPCHECK(hipMemcpyAsync(sorted_ids, c->ids[1].p, (size_t)sv.count * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHECK(hipMemsetAsync(fe_kred(c), 0, sizeof slots, st));
+    c->have_fwd = false;                                                    // the forward state of the context is gone
     return DVS_OK;
 }
 
@@ -770,6 +807,11 @@ int dvs_get_num_rendered(dvs_ctx* c, void* stream, uint64_t* T) {
 }
 
 int dvs_get_sort_rank_mode(dvs_ctx* c) { return c ? c->fe_rank_atomic : -1; }
+int dvs_set_export_sorted_tiles(dvs_ctx* c, int enable) {
+    if (!c) { g_last_error = "dvs_set_export_sorted_tiles: null context"; return DVS_ERR_INVALID; }
+    c->export_tiles = enable != 0;
+    return DVS_OK;
+}
 
 int dvs_get_arena_info(dvs_ctx* c, uint64_t* cap, uint64_t* grows, uint64_t* last_T, uint64_t* overflows) {
     if (!c) { g_last_error = "dvs_get_arena_info: null context"; return DVS_ERR_INVALID; }

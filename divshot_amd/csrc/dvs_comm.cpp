@@ -8,6 +8,7 @@
 #include <netinet/in.h>
 #include <sys/socket.h>
 #include <unistd.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -116,8 +117,15 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
         set_timeouts(ls, 1);                                   // accept() wakes up once a second to check the deadline
         std::vector<bool> served((size_t)world, false);
         int left = world - 1;
-        while (left > 0) {
-            if (now_s() > deadline) { err = "timed out waiting for " + std::to_string(left) + " rank(s) to fetch the RCCL id"; ::close(ls); return false; }
+        // the unrecoverable failure used to sit on the LAST message — a peer whose receive of the confirmation fails after we
+        // counted it would retry against a closed listener until its deadline while every other rank already waits in ncclCommInitRank
+        // (which has no timeout). Two measures: the peer waits for the confirmation with the whole remaining deadline (below), and the
+        // listener stays open for a grace period after the last rank was counted and answers already-served ranks again.
+        double grace_until = 0.0;
+        const double grace_s = [] { const char* e = getenv("DVS_COMM_GRACE_S"); const double v = e ? atof(e) : 1.0; return v >= 0.0 ? v : 1.0; }();
+        while (left > 0 || now_s() < grace_until) {
+            if (left > 0 && now_s() > deadline) { err = "timed out waiting for " + std::to_string(left) + " rank(s) to fetch the RCCL id"; ::close(ls); return false; }
+            if (left == 0) { timeval tv{}; tv.tv_usec = 100000; setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv); }      // grace period: 0.1 s ticks
             int fd = ::accept(ls, nullptr, nullptr);
             if (fd < 0) continue;                              // timeout tick / transient error
             set_timeouts(fd, 5);
@@ -133,7 +141,7 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
                 const uint8_t confirm = 1;                     // a peer that has read this last byte returns "ok" — if our receive of the ack
                                                                // fails the byte is never sent, the peer times out on it and asks again
                 if (send_all(fd, &r, sizeof r) && recv_all(fd, &ack, sizeof ack) && ack == kMagic && send_all(fd, &confirm, 1)) {
-                    if (!served[h.rank]) { served[h.rank] = true; --left; }
+                    if (!served[h.rank]) { served[h.rank] = true; --left; if (left == 0) grace_until = std::min(deadline, now_s() + grace_s); }
                     if (keep_fds) { int& slot = (*keep_fds)[h.rank]; if (slot >= 0) ::close(slot); slot = fd; kept = true; }
                 }
             } else if (got && h.magic == kMagic) {
@@ -160,7 +168,10 @@ bool exchange_id(void* id128, int rank, int world, const char* addr, int port, u
                 const uint32_t ack = kMagic;
                 uint8_t confirm = 0;                           // three-way: hello -> id -> ack -> confirm. Without the confirm rank 0 has not counted us
                                                                // (its receive of the ack failed): ask again instead of walking into ncclCommInitRank alone
-                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic && send_all(fd, &ack, sizeof ack) &&
+                // (the confirmation is awaited with everything the deadline has left, not the 5 s step timeout: once the ack is out rank 0
+                // may have counted us, and giving up on this connection then is the one failure the others cannot recover from)
+                auto wait_long = [&] { const double rem = deadline - now_s(); set_timeouts(fd, rem > 1.0 ? (int)rem : 1); return true; };
+                if (send_all(fd, &h, sizeof h) && recv_all(fd, &r, sizeof r) && r.magic == kMagic && send_all(fd, &ack, sizeof ack) && wait_long() &&
                     recv_all(fd, &confirm, 1) && confirm == 1) { memcpy(id128, r.id, 128); ok = true; }
             }
             if (ok && keep_fds) { (*keep_fds)[0] = fd; continue; }

@@ -45,7 +45,8 @@ void      dvs_comm_destroy(dvs_comm* comm);
 int       dvs_comm_rank(const dvs_comm* comm);
 int       dvs_comm_world(const dvs_comm* comm);
 /* What the BACKEND says: the size the RCCL communicator reports (ncclCommCount; -1 if this librccl has no such call), or — test backend —
- * the ranks rank 0 holds a socket to (+ itself). bench.py prints it as `rccl_nranks`: "RCCL saw N ranks" readable without the source. */
+ * the ranks rank 0 holds a socket to (+ itself); on the OTHER ranks of the test backend it is the world size they were started with,
+ * unverified (only rank 0 sees every socket). bench.py prints rank 0's value as `rccl_nranks`: "RCCL saw N ranks" readable without the source. */
 int       dvs_comm_backend_ranks(const dvs_comm* comm);
 const char* dvs_comm_backend_name(const dvs_comm* comm);      /* "rccl" | "tcp (host-staged TEST backend)" */
 

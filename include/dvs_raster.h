@@ -142,7 +142,9 @@ typedef struct dvs_fwd_state {
     const uint32_t* tiles_touched;  /* [n] */
     /* per instance (num_rendered), sorted by (tile, depth, splat id) */
     const uint32_t* sorted_tile;    /* [T] tile id of each sorted instance (a batch: view * tiles + tile). NULL after an ASYNCHRONOUS forward
-                                       (dvs_set_async): the ids are then not written at all — the list is grouped by tile, `ranges` says where */
+                                       (dvs_set_async): the ids are then not written at all — the list is grouped by tile, `ranges` says where —
+                                       unless dvs_set_export_sorted_tiles(ctx, 1) asked for them. (ABI note, round 5: before that round the pointer
+                                       was always valid; a consumer of this struct that runs asynchronous forwards must check it or set the switch.) */
     const uint32_t* sorted_splat;   /* [T] splat id ("value") of each sorted instance */
     /* per tile */
     const uint32_t* ranges;         /* [tiles,2] [start,end) into the sorted lists */
@@ -184,7 +186,8 @@ int dvs_raster_forward(dvs_ctx* ctx, void* stream, const dvs_splats* params, con
                        const dvs_opts* opts, float* out_rgb, dvs_fwd_state* saved, uint64_t* num_rendered);
 
 /* Backward: A8 composite backward -> A9 preprocess backward, using the state of the last forward on ctx.
- *   dL_drgb: DEVICE [3,H,W] planar fp32.  out: gradient rows (see dvs_splat_grads). Asynchronous. */
+ *   dL_drgb: DEVICE [3,H,W] planar fp32, 16-byte aligned like every device array of this interface (DVS_ERR_INVALID otherwise: the
+ *   composite backward reads it as 16-byte words).  out: gradient rows (see dvs_splat_grads). Asynchronous. */
 int dvs_raster_backward(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cam,
                         const dvs_opts* opts, const float* dL_drgb, const dvs_splat_grads* out);
 
@@ -262,6 +265,10 @@ int dvs_get_arena_info(dvs_ctx* ctx, uint64_t* instance_capacity, uint64_t* grow
  * the lanes that add to one LDS address in lane order — probed on the device, csrc/frontend.hip), 0 = ballot multisplit (the fallback,
  * and what DVS_FE_RANK=ballot forces). Both give the same stable order; the parity suite runs both. -1 for a NULL context. */
 int dvs_get_sort_rank_mode(dvs_ctx* ctx);
+/* Asynchronous forwards (dvs_set_async) normally leave dvs_fwd_state.sorted_tile NULL: the tile sort's last pass builds the tile ranges
+ * itself and skips the 4 B per instance nobody reads. enable = 1 makes them write the sorted tile ids again (for a caller that exports the
+ * lists, e.g. dvs_export_sorted_keys, without giving up the asynchronous mode); costs ~10 us per 8-view step at C3. Default 0. */
+int dvs_set_export_sorted_tiles(dvs_ctx* ctx, int enable);
 
 /* TEST HOOK of the parity suite. While take_masks is non-NULL, every single-view synchronous forward on the context (default A7 kernel)
  * also records ITS OWN threshold decisions: take_masks[4 * j + q] (device memory, 8-byte aligned, capacity_instances * 4 words, zeroed by
@@ -270,6 +277,12 @@ int dvs_get_sort_rank_mode(dvs_ctx* ctx);
  * disagreement between an fp32 and an fp64 rasterizer — a threshold passed on one side and missed on the other — so that EVERY splat
  * is held to the 1e-4 bar (tests/test_gpu_parity.py). Same arithmetic and images as without it; NULL switches it off. */
 int dvs_debug_record_decisions(dvs_ctx* ctx, uint64_t* take_masks, uint64_t capacity_instances);
+/* TEST HOOK. Runs the forward's depth sort (A5, low 32 key bits: three passes whose digit width follows the key range — frontend.hip) on
+ * caller-supplied DEVICE keys of ONE view: keys[n] as the projection would leave them (float bits of the depth; 0xFFFFFFFF = culled, those
+ * leave in the first pass). sorted_ids[n_sorted] receives the indices of the surviving keys in stable ascending key order, *digit_bits the
+ * digit width the range selected (9 up to a ratio of 2^12.5 between the keys' extremes, 11 for the full 31 bits — a range the projection
+ * itself cannot produce, which is why the widest digit is reached through this hook only). Synchronises; invalidates the forward state. */
+int dvs_debug_sort_depth_keys(dvs_ctx* ctx, void* stream, const uint32_t* keys, uint64_t n, uint32_t* sorted_ids, uint32_t* n_sorted, uint32_t* digit_bits);
 
 /* The library ships ONE composite forward (A7, "quadrant") and ONE composite backward (A8, "tr"), plus the round-2 backward "blocks" as
  * the independent-summation-order cross-check of the parity tests. The other measured alternatives of DESIGN.md §5 — backward "reduce"

@@ -228,6 +228,8 @@ template <class T> struct State {
     std::vector<uint64_t> keys;          // sorted
     std::vector<uint32_t> vals;          // sorted
     std::vector<uint32_t> ranges;        // [tiles,2]
+    std::vector<uint32_t> forced_vals, forced_ranges;   // tests (dvso_set_lists): composite over THESE tile lists instead of binning — the fp64
+                                         // instantiation over the lists of the fp32 run, when a radius on an integer boundary makes fp64 bin differently
     // A7
     std::vector<T> out_color, final_T;   // [3,H,W], [H,W]
     std::vector<uint32_t> n_contrib;

@@ -57,17 +57,31 @@ void dvso_destroy(void* hp) { delete (Handle*)hp; }
 int dvso_forward(void* hp, int n, const void* pos, const void* sh0, const void* shN, const void* opacity,
                  const void* scale, const void* rot, const dvs_camera* cam, const dvs_opts* opts) {
     Handle* h = (Handle*)hp;
-    if (h->is_double) {
-        load_inputs(h->d, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
-        dvso::preprocess_forward(h->d); dvso::bin(h->d);
-        if (!h->d.replay.empty() && h->d.replay.size() != 4 * h->d.vals.size()) return 2;     // the recorded lists are not this scene's
-        dvso::render_forward(h->d);
-    } else {
-        load_inputs(h->f, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
-        dvso::preprocess_forward(h->f); dvso::bin(h->f);
-        if (!h->f.replay.empty() && h->f.replay.size() != 4 * h->f.vals.size()) return 2;
-        dvso::render_forward(h->f);
-    }
+    auto run = [&](auto& S) -> int {
+        load_inputs(S, n, pos, sh0, shN, opacity, scale, rot, cam, opts);
+        dvso::preprocess_forward(S);
+        if (S.forced_ranges.empty()) dvso::bin(S);
+        else {
+            // the lists of another run of the same scene (dvso_set_lists): no binning. Every listed splat must be visible here too
+            // (a splat this precision culls has no projected record to composite): 3 = it is not, 4 = the ranges are not this image's
+            if (S.forced_ranges.size() != 2 * (size_t)S.tiles_x * S.tiles_y) return 4;
+            for (uint32_t id : S.forced_vals) if (id >= (uint32_t)S.n || S.radii[id] <= 0) return 3;
+            S.vals = S.forced_vals; S.ranges = S.forced_ranges; S.keys.clear();
+        }
+        if (!S.replay.empty() && S.replay.size() != 4 * S.vals.size()) return 2;     // the recorded lists are not this scene's
+        dvso::render_forward(S);
+        return 0;
+    };
+    return h->is_double ? run(h->d) : run(h->f);
+}
+
+// From now on dvso_forward composites over the given tile lists (vals[count]: splat ids in list order; ranges[2 * tiles]: (start, end) per
+// tile — the layout of dvso_array("vals") / ("ranges")) instead of binning the scene itself. count = n_ranges = 0 clears. Used by the parity
+// tests to run the fp64 instantiation over the lists of the fp32 / HIP run when fp64 bins a splat differently.
+int dvso_set_lists(void* hp, const uint32_t* vals, uint64_t count, const uint32_t* ranges, uint64_t n_ranges) {
+    Handle* h = (Handle*)hp;
+    h->f.forced_vals.assign(vals, vals + count); h->d.forced_vals.assign(vals, vals + count);
+    h->f.forced_ranges.assign(ranges, ranges + n_ranges); h->d.forced_ranges.assign(ranges, ranges + n_ranges);
     return 0;
 }
 

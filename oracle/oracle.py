@@ -36,6 +36,8 @@ def _load():
         _lib.dvso_record_masks.argtypes = [C.c_void_p, C.c_int]
         _lib.dvso_set_replay.restype = C.c_int
         _lib.dvso_set_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        _lib.dvso_set_lists.restype = C.c_int
+        _lib.dvso_set_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         _lib.dvso_array.restype = C.c_void_p
         _lib.dvso_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib.dvso_interactions.restype = C.c_uint64
@@ -85,7 +87,8 @@ class Oracle:
         # (grad_mode: 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE — only the backward differs)
         self.W, self.H = cam.width, cam.height
         rc = self.lib.dvso_forward(self.h, n, *[a.ctypes.data for a in arrs], C.addressof(cam), C.addressof(opts))
-        assert rc == 0, "the recorded decisions do not belong to these tile lists" if rc == 2 else rc
+        assert rc == 0, {2: "the recorded decisions do not belong to these tile lists", 3: "set_lists: a listed splat is culled in this precision",
+                         4: "set_lists: the ranges are not this image's"}.get(rc, rc)
         return self.get("out_color").reshape(3, self.H, self.W)
 
     def record_masks(self, on=True):
@@ -98,6 +101,14 @@ class Oracle:
         the alpha / transmittance thresholds (None or an empty array: back to the oracle's own decisions)."""
         m = np.ascontiguousarray(masks if masks is not None else np.zeros((0, 4)), dtype=np.uint64)
         assert self.lib.dvso_set_replay(self.h, m.ctypes.data, m.size) == 0
+
+    def set_lists(self, vals, ranges):
+        """From now on forward() composites over these tile lists (vals: splat ids in list order; ranges: [tiles, 2]) instead of binning
+        the scene itself — e.g. the float64 oracle over the float32 run's lists when a radius on an integer boundary makes float64 bin a
+        splat differently. None, None: back to its own binning."""
+        v = np.ascontiguousarray(vals if vals is not None else np.zeros(0), dtype=np.uint32)
+        r = np.ascontiguousarray(ranges if ranges is not None else np.zeros(0), dtype=np.uint32)
+        assert self.lib.dvso_set_lists(self.h, v.ctypes.data, v.size, r.ctypes.data, r.size) == 0
 
     def backward(self, dL_dout, grad_mode=None):
         """grad_mode: None = the mode given to forward(); 0 = DVS_GRAD_TRUE, 1 = DVS_GRAD_LINEAGE (the forward does not depend on it)."""

@@ -71,6 +71,50 @@ def test_three_ranks_next_to_a_busy_master_port_with_strays():
         assert got == want
 
 
+def test_listener_answers_a_served_rank_again_during_the_grace_period():
+    """a peer whose receive of rank 0's confirmation failed AFTER rank 0 counted it used to retry against a closed listener
+    while every other rank already sat in ncclCommInitRank. Rank 0 now keeps the listener open for a grace period (DVS_COMM_GRACE_S,
+    default 1 s) after the last rank was counted and answers already-served ranks again. Played with a raw socket as rank 1 of 2:
+    complete handshake, then the same hello once more — the id and the confirmation come back a second time."""
+    port = _free_port()
+    boot = port + 1789 if port + 1789 < 65536 else 1024 + (port + 1789 - 65536) % (65536 - 1024)
+    r0 = _spawn(0, 2, port, {"DVS_COMM_GRACE_S": "6", "DVS_COMM_NONCE": "grace-test"})
+    import hashlib
+    key = (":" + str(port) + "|grace-test").encode()
+    h = 1469598103934665603
+    for ch in key:
+        h ^= ch; h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF                      # FNV-1a, as dvs_comm.cpp job_nonce()
+    want = bytes((7 * i + 3) % 251 for i in range(128))
+
+    def handshake():
+        deadline = time.time() + 30
+        while True:
+            try:
+                s = socket.create_connection(("127.0.0.1", boot), timeout=5); break
+            except OSError:
+                assert time.time() < deadline, "rank 0 does not listen"
+                time.sleep(0.1)
+        s.sendall(struct.pack("<IIQ", 0x44565343, 1, h))
+        buf = b""
+        while len(buf) < 136:
+            chunk = s.recv(136 - len(buf)); assert chunk, "rank 0 closed the connection before the id"
+            buf += chunk
+        assert struct.unpack("<I", buf[:4])[0] == 0x44565343 and buf[8:] == want
+        s.sendall(struct.pack("<I", 0x44565343))
+        assert s.recv(1) == b"\x01"
+        s.close()
+
+    env_keys = [k for k in ("TORCHELASTIC_RUN_ID", "SLURM_JOB_ID") if k in os.environ]
+    if env_keys:
+        import pytest
+        pytest.skip("the job nonce also hashes " + ", ".join(env_keys))
+    handshake()                  # rank 0 has now counted its only peer
+    time.sleep(0.3)
+    handshake()                  # ... and still answers it (before round 6: connection refused)
+    rc, got, msg = _result(r0)
+    assert rc == 0, msg
+
+
 def test_missing_rank_times_out_with_an_error():
     port = _free_port()
     t0 = time.time()

@@ -7,6 +7,7 @@ against the fp64 oracle: every element within 1e-4 rel + 1e-5 of the group's max
 for sums that cancel: a per-splat gradient is a sum of hundreds of signed per-pixel terms accumulated in
 fp32), and the whole group within 1e-5 relative L2 error.
 """
+import ctypes as C
 import json
 import os
 import numpy as np
@@ -198,11 +199,25 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     rast.record_decisions(0)
     o64 = oracle_mod.Oracle(np.float64)
     o64.forward(P, cam, sh_degree=deg, antialias=aa)
-    same_lists = np.array_equal(o64.get("vals"), o.get("vals")) and np.array_equal(o64.get("ranges"), o.get("ranges"))
-    # (fp64 can bin differently when a radius sits on an integer boundary: the fp32 oracle — same lists as the HIP path — replays then)
-    orp = oracle_mod.Oracle(np.float64 if same_lists else np.float32)
+    own_lists = np.array_equal(o64.get("vals"), o.get("vals")) and np.array_equal(o64.get("ranges"), o.get("ranges"))
+    # fp64 can bin a splat differently when a radius sits on an integer boundary (C3 and the C5 shape at full size). Rounds 4-5 fell back
+    # to the fp32 replay alone there, so the HIP-vs-fp64 figures were missing for exactly the two configurations that matter most. Since
+    # round 6 the fp64 instantiation then composites over the fp32 / HIP LISTS (Oracle.set_lists) and replays the recorded decisions on them:
+    # what differs between the two is again the arithmetic alone. (A splat fp64 culls but fp32 lists cannot be composited: fp32 replay then.)
+    orp = oracle_mod.Oracle(np.float64)
+    same_lists = True
+    if not own_lists:
+        orp.set_lists(o.get("vals"), o.get("ranges"))
     orp.set_replay(masks)
-    img_r = orp.forward(P, cam, sh_degree=deg, antialias=aa)
+    try:
+        img_r = orp.forward(P, cam, sh_degree=deg, antialias=aa)
+    except AssertionError as e:
+        if own_lists or "culled in this precision" not in str(e):
+            raise
+        same_lists = False
+        orp = oracle_mod.Oracle(np.float32)
+        orp.set_replay(masks)
+        img_r = orp.forward(P, cam, sh_degree=deg, antialias=aa)
     assert np.array_equal(orp.get("n_contrib"), saved["n_contrib"]), "replayed decisions do not reproduce n_contrib"
     # A7 on EVERY pixel, fragile or not: against the fp32 oracle replaying the same decisions — the specification of the composite
     # arithmetic on bit-identical projected splats (an fp64 projection moves a sharp splat's alpha by up to 1e-4 through the rounding of
@@ -222,7 +237,10 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     m, worst = rel_close(saved["final_T"], fT_r32, 1e-4, 1e-6)
     assert m.all(), f"final_T (replay, all pixels) worst {worst}"
     m, worst = rel_close(img, img_r, 1e-3, 1e-5)                       # and the fp64 replay at the looser bar that input rounding allows
-    assert m.all(), f"rgb (fp64 replay, all pixels) worst {worst}"
+    # (full size: millions of pixels behind lists of hundreds of sharp splats — at most 1e-5 of the values may miss that bar, none by more
+    # than 10x; the strict comparison of every pixel is the fp32 replay above)
+    n_px_out, px_allowed = int((~m).sum()), (int(1e-5 * m.size) if n >= 500000 else 0)
+    assert n_px_out <= px_allowed and worst <= (10.0 if px_allowed else 1.0), f"rgb (fp64 replay, all pixels): {n_px_out} of {m.size} values beyond the bar (allowed {px_allowed}), worst {worst}"
     frag_any = frag | o64.get("fragile").astype(bool)
     capf = orp.get("cap_fragile").astype(bool)
     tainted = np.zeros(n, bool)
@@ -244,7 +262,9 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
     clean_early = clean
     report = {"config": name, "n": n, "visible": int((saved["radii"] > 0).sum()), "T": int(rast.num_rendered),
               "fragile_pixel_fraction": float(frag_any.mean()), "tainted_splat_fraction": float(tainted.mean()),
-              "decision_replay": "fp32 strict + fp64 wide" if same_lists else "fp32 (fp64 bins differently)", "cap_fragile_pixel_fraction": float(capf.mean()), "runs": {}}
+              "decision_replay": ("fp32 strict + fp64 wide" + ("" if own_lists else " (fp64 composites over the fp32 lists: it bins a splat differently)")) if same_lists
+                                 else "fp32 (a listed splat is culled in fp64)", "cap_fragile_pixel_fraction": float(capf.mean()),
+              "rgb_vs_fp64_replay": {"values_beyond_1e-3": n_px_out, "of": int(m.size), "worst_err_over_tol": worst}, "runs": {}}
 
     # Untainted splats: strict, against fp64. Tainted splats (a fragile pixel in the footprint, where the HIP path may
     # legitimately take the other branch of a threshold than either oracle): the whole tainted set within 1e-3 relative L2
@@ -274,6 +294,7 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
 
     culled = saved["radii"] == 0
     oracle_grads = {}
+    o_l2, o_out = {}, {}                       # (mode, group) -> relative L2 / (outliers, worst) between the fp32 and the fp64 oracle replay
     for mode in (0, 1):
         # strict reference: the fp32 oracle replaying the HIP path's own decisions — the specification evaluated on bit-identical
         # projected splats with identical contributor sets (what is compared is the arithmetic alone). The fp64 replay is checked
@@ -289,8 +310,22 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
             for k in KEYS:
                 a, b = ref64[k][clean_early], wide[k][clean_early]
                 l2 = np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
-                assert l2 < 1e-4, f"fp32 replay vs fp64 replay, mode {mode}, {k}: relative L2 {l2}"
-                assert (np.abs(a - b) <= 10 * (1e-4 * np.abs(b) + 1e-5 * np.abs(wide[k]).max())).all(), (mode, k)
+                # relative L2 < 1e-4 per group between the two ORACLE precisions; at full size the position group is input-rounding-bound
+                # (C5 shape: 2.1e-4 — splats half as large at twice the resolution, the fp32 rounding of a mean moves alpha by more): there the
+                # figure is recorded, bounded by 1e-3, and becomes the yardstick of the HIP-vs-fp64 assertion below
+                o_l2[(mode, k)] = float(l2)
+                assert l2 < (1e-4 if n < 500000 else 1e-3), f"fp32 replay vs fp64 replay, mode {mode}, {k}: relative L2 {l2}"
+                ratio = np.abs(a - b) / (10 * (1e-4 * np.abs(b) + 1e-5 * np.abs(wide[k]).max()) + 1e-300)
+                # Every element within 10x the strict tolerance — at full size (3 M elements per group) with a stated allowance: the two
+                # ORACLE precisions themselves differ by up to 12.8x on 6 of 2 999 862 position elements of C3 (sharp splats behind hundreds of
+                # contributors: the fp32 rounding of the inputs), and by up to 53x on 626 of 15 M at the C5 shape, so there at most 1e-4 of a group's elements may lie
+                # between 10x and 100x, none beyond; the count and the worst ratio go into the report and bound what the HIP path may show below.
+                n_out, allowed = int((ratio > 1).sum()), (int(1e-4 * ratio.size) if n >= 500000 else 0)
+                o_out[(mode, k)] = (n_out, float(ratio.max()) * 10)
+                report.setdefault("fp32_vs_fp64_replay", {})[f"mode{mode}/{k}"] = {"rel_l2": float(l2), "worst_err_over_strict_tol": float(ratio.max()) * 10,
+                                                                                   "elements_beyond_10x": n_out, "of": int(ratio.size)}
+                assert n_out <= allowed and (ratio <= 10.0).all(), (f"fp32 replay vs fp64 replay, mode {mode}, {k}: {n_out} of {ratio.size} elements beyond 10x the "
+                                                                    f"strict tolerance (allowed {allowed}), worst {float(ratio.max()) * 10:.1f}x")
         ref32 = {k: v.copy() for k, v in o.backward(dL, grad_mode=mode).items()}
         inter32 = {k: o.get(k).copy() for k in ("dL_dmean2d", "dL_dconic_opacity", "dL_drgb", "absgrad")}
         oracle_grads[mode] = ref64
@@ -312,9 +347,17 @@ def check_pipeline_parity(rast, oracle_mod, name, cfg, variants=None, n_cams=1, 
                     a, b = np.asarray(grads[k], np.float64)[clean_early], wide[k][clean_early]
                     l2 = np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
                     worst = float((np.abs(a - b) / (1e-4 * np.abs(b) + 1e-5 * np.abs(wide[k]).max() + 1e-300)).max()) if a.size else 0.0      # (all-zero group: SH bands above the degree)
-                    rec[tag + "grad " + k + " vs fp64 replay"] = {"rel_l2": float(l2), "worst_err_over_strict_tol": worst}
-                    assert l2 < 1e-4, f"{tag}{k}: HIP vs fp64 replay relative L2 {l2}"
-                    assert worst <= 10.0, f"{tag}{k}: HIP vs fp64 replay worst element {worst} x the strict tolerance"
+                    r_ = np.abs(a - b) / (1e-4 * np.abs(b) + 1e-5 * np.abs(wide[k]).max() + 1e-300) if a.size else np.zeros(1)
+                    oo = o_out.get((mode, k), (0, 0.0))       # full size: no more outliers than the fp32 specification itself has against fp64 (+ 25 %)
+                    n_out, allowed = int((r_ > 10.0).sum()), (int(1.25 * oo[0]) + 10 if n >= 500000 else 0)
+                    rec[tag + "grad " + k + " vs fp64 replay"] = {"rel_l2": float(l2), "worst_err_over_strict_tol": worst, "elements_beyond_10x": n_out, "of": int(r_.size)}
+                    # the HIP path must be as close to fp64 as the fp32 SPECIFICATION is: 1e-4, or — where input rounding alone puts the
+                    # fp32 oracle further out (full-size position gradients) — within 25 % of the fp32 oracle's own distance
+                    bar = max(1e-4, 1.25 * o_l2.get((mode, k), 0.0))
+                    rec[tag + "grad " + k + " vs fp64 replay"]["fp32_oracle_vs_fp64_rel_l2"] = o_l2.get((mode, k))
+                    assert l2 < bar, f"{tag}{k}: HIP vs fp64 replay relative L2 {l2} (bar {bar})"
+                    assert n_out <= allowed and worst <= max(10.0, 1.25 * oo[1]), (f"{tag}{k}: HIP vs fp64 replay: {n_out} elements beyond 10x (allowed {allowed}), worst {worst} x "
+                                                                                     f"the strict tolerance (fp32 oracle vs fp64: {oo[0]} elements, worst {oo[1]})")
             for k in KEYS:       # culled splats get exactly zero rows
                 assert not np.any(grads[k][culled]), k
     # the size of the ambiguity between the two backward definitions on this scene (fp64 oracle): relative L2 per group
@@ -621,6 +664,45 @@ def test_sort_pairs(rast):
         np.testing.assert_array_equal(v_d.cpu().numpy().view(np.uint32), vals[order])
 
 
+def test_depth_sort_widest_digits_through_the_test_hook(gpu_device):
+    """the scatter's wide path with 11-bit digits (key ranges of 31 bits) cannot be reached through the projection — its squares
+    overflow beyond z ~ 1e19 — so dvs_debug_sort_depth_keys drives the forward's three-pass range-adaptive depth sort directly: synthetic
+    keys spanning 8 ... 31 bits (digit widths 3 ... 11, i.e. the LDS-reordering path up to 9 bits and the straight-from-registers path
+    above), with culled keys (0xFFFFFFFF), many exact ties and both partition sizes, in both rank modes, against numpy's stable argsort."""
+    import torch
+    from divshot_amd.raster import Rasterizer
+    rng = np.random.default_rng(5)
+    old = os.environ.get("DVS_FE_RANK")
+    try:
+        for mode in ("default", "ballot"):
+            if mode == "ballot": os.environ["DVS_FE_RANK"] = "ballot"
+            else: os.environ.pop("DVS_FE_RANK", None)
+            r = Rasterizer(0, max_splats=1 << 21, max_w=64, max_h=64)
+            for n in (70_001, 1_700_000):
+                for span_bits in (8, 20, 27, 28, 30, 31):
+                    lo = np.uint32(rng.integers(1, 1 << 20)) if span_bits < 31 else np.uint32(1)
+                    keys = (lo + rng.integers(0, (1 << span_bits) - int(lo if span_bits == 31 else 0), n, dtype=np.uint64)).astype(np.uint32)
+                    keys[rng.integers(0, n, n // 4)] = keys[1]                    # exact ties: stability matters
+                    keys[0], keys[-1] = lo, np.uint32(int(lo) + (1 << span_bits) - 1 - int(lo if span_bits == 31 else 0))      # the extremes are present
+                    keys[rng.integers(0, n, n // 7)] = 0xFFFFFFFF               # culled
+                    k_d = torch.from_numpy(keys.view(np.int32).copy()).to(r.tdev)
+                    out = torch.empty(n, dtype=torch.int32, device=r.tdev)
+                    cnt, bits = C.c_uint32(0), C.c_uint32(0)
+                    rc = dv.lib.dvs_debug_sort_depth_keys(r.ctx, None, k_d.data_ptr(), n, out.data_ptr(), C.byref(cnt), C.byref(bits))
+                    assert rc == 0, dv.lib.dvs_last_error()
+                    vis = np.where(keys != 0xFFFFFFFF)[0]
+                    want = vis[np.argsort(keys[vis], kind="stable")]
+                    assert cnt.value == vis.size
+                    rb = int(keys[vis].max() - keys[vis].min()).bit_length()
+                    assert bits.value == max(1, (rb + 2) // 3), (span_bits, bits.value)
+                    np.testing.assert_array_equal(out.cpu().numpy()[:cnt.value].view(np.uint32), want.astype(np.uint32), err_msg=f"{mode} n={n} span={span_bits}")
+                    if span_bits == 31: assert bits.value == 11
+            r.close()
+    finally:
+        if old is None: os.environ.pop("DVS_FE_RANK", None)
+        else: os.environ["DVS_FE_RANK"] = old
+
+
 def test_sort_rank_modes_agree(gpu_device):
     """Round 6: the scatters of both radix sorts rank inside a wave by returning LDS adds when the device serves the lanes of one LDS
     address in lane order (probed on the device at dvs_create: dvs_get_sort_rank_mode == 1), else by the ballot multisplit of rounds
@@ -747,6 +829,17 @@ def test_async_forward_no_host_sync(gpu_device):
     for k in KEYS:
         m, worst = rel_close(g_a[k].cpu().numpy(), g_s[k].cpu().numpy(), 1e-4, 2e-6)       # fp32 atomics: not bit-reproducible
         assert m.all(), (k, worst)
+    # the asynchronous forward does not materialise the sorted tile ids (dvs_fwd_state.sorted_tile NULL) unless asked to
+    from divshot_amd import _lib as _l
+    st_ = _l.FwdState()
+    assert dv.lib.dvs_get_view_state(r.ctx, 0, C.byref(st_)) == 0 and not st_.sorted_tile
+    assert dv.lib.dvs_set_export_sorted_tiles(r.ctx, 1) == 0
+    img_e = r.forward(Pd, cam, sh_degree=2, absgrad=True)
+    assert r.get_num_rendered() == T_sync and torch.equal(img_e, img_s)
+    assert dv.lib.dvs_get_view_state(r.ctx, 0, C.byref(st_)) == 0 and st_.sorted_tile
+    exported = r._d2h(st_.sorted_tile, (T_sync,), np.uint32)
+    np.testing.assert_array_equal(exported, saved_s["sorted_tile"])
+    assert dv.lib.dvs_set_export_sorted_tiles(r.ctx, 0) == 0
     r.close()
     # overflow: splats covering ~30 tiles each against an arena sized for 5 per splat
     spec = dv.make_spec(8000, 640, 480, sh_degree=0, seed=4, scale_log_offset=2.2)

@@ -122,3 +122,52 @@ def test_decision_replay_reproduces_the_recorded_run(oracle_mod):
         o64.set_replay(None)
         again = o64.forward(P, cam, sh_degree=deg)
         assert np.array_equal(again, own)              # replay off: the oracle's own decisions again
+
+
+def test_set_lists_composites_over_foreign_tile_lists(oracle_mod):
+    """Oracle.set_lists (round 6; what the GPU parity suite uses at C3 / C5 size, where a radius on an integer boundary makes float64 bin one
+    splat differently from float32): the float64 oracle composites over the FLOAT32 run's tile lists and replays its decisions. Forced here
+    with a splat whose float32 radius is one more than its float64 radius would be hard to construct, so the lists are made foreign another
+    way that must not change a single pixel: every tile's list gets the same entries as the oracle's own, handed over explicitly — image,
+    n_contrib and gradients must be bit-identical to the run that binned by itself; then a list with one entry REMOVED changes exactly the
+    pixels of that tile; a listed splat that the run culls, and ranges of another image size, are refused."""
+    from util import scene
+    Oracle = oracle_mod.Oracle
+    spec, P, cam, tgt = scene(1500, 80, 48, 2, 9)
+    o = Oracle(np.float64)
+    img = o.forward(P, cam, sh_degree=2).copy()
+    vals, ranges, nc = o.get("vals").copy(), o.get("ranges").copy(), o.get("n_contrib").copy()
+    dL = np.random.default_rng(1).normal(size=img.shape)
+    g = {k: v.copy() for k, v in o.backward(dL).items()}
+    f = Oracle(np.float64)
+    f.set_lists(vals, ranges)
+    img_f = f.forward(P, cam, sh_degree=2)
+    assert np.array_equal(img_f, img) and np.array_equal(f.get("n_contrib"), nc) and f.get("keys").size == 0
+    gf = f.backward(dL)
+    for k in g:
+        assert np.array_equal(gf[k], g[k]), k
+    # the float32 oracle's lists under the float64 composite: same lists here (small scene), so again the same image
+    o32 = Oracle(np.float32); o32.forward(P, cam, sh_degree=2)
+    if np.array_equal(o32.get("vals"), vals):
+        f.set_lists(o32.get("vals"), o32.get("ranges"))
+        assert np.array_equal(f.forward(P, cam, sh_degree=2), img)
+    # drop the first entry of the fullest tile: only that tile's pixels may change
+    t = int(np.argmax(ranges[:, 1] - ranges[:, 0]))
+    r2 = ranges.copy(); r2[t, 0] += 1
+    f.set_lists(vals, r2)
+    img2 = f.forward(P, cam, sh_degree=2)
+    tx, ty = t % 5, t // 5
+    changed = np.abs(img2 - img).max(axis=0) > 0
+    assert changed.any() and not changed[:ty * 16].any() and not changed[(ty + 1) * 16:].any() and not changed[:, :tx * 16].any() and not changed[:, (tx + 1) * 16:].any()
+    # refusals
+    culled = np.where(o.get("radii") == 0)[0]
+    if culled.size:
+        bad = vals.copy(); bad[0] = culled[0]
+        f.set_lists(bad, ranges)
+        with pytest.raises(AssertionError, match="culled in this precision"):
+            f.forward(P, cam, sh_degree=2)
+    f.set_lists(vals, ranges[:-1])
+    with pytest.raises(AssertionError, match="not this image"):
+        f.forward(P, cam, sh_degree=2)
+    f.set_lists(None, None)
+    assert np.array_equal(f.forward(P, cam, sh_degree=2), img) and f.get("keys").size == vals.size

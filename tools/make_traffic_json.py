@@ -3,9 +3,24 @@
 usage: tools/make_traffic_json.py pmc_fetch.txt pmc_write.txt [steps_of_the_profiled_command] > profiles/rNN_traffic.json
 With the step count of the profiled bench command (tools/pmc.sh: 3 timed + 1 warm-up = 4) every kernel also gets launches_per_step
 (= calls / steps; kernels launched fewer times than there were steps are set-up work) and the file a counter_bytes_per_step total."""
+import glob
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources the counters were collected on (divshot_amd/csrc: *.hip, *.h, *.cpp, sorted by name) — bench.py
+    recomputes it and says whether the committed counters still belong to the code it is timing."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse(path, counter):
@@ -45,7 +60,7 @@ def main():
            "reports half the bytes of wide coalesced reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibrated on "
            "k_preprocess_fwd (236 B read per splat). The factor 2 is NOT calibrated for the narrow gathers of the composite kernels "
            "(their figure is an upper bound), the counters include Infinity-Cache hits, and cross-XCD fp32 atomics are counted as writes.")
-    out = {"_how": how, "workload": "C3", "views_per_launch": 8, "kernels": kernels}
+    out = {"_how": how, "workload": "C3", "views_per_launch": 8, "kernel_source_sha16": kernel_source_sha(), "kernels": kernels}
     if steps:
         out["steps_of_profiled_command"] = steps
         out["counter_bytes_per_step"] = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_per_step"] for v in kernels.values()
