@@ -71,6 +71,8 @@ _PROTOS = {
     "dvs_create_views": (C.c_void_p, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "dvs_destroy": (None, [C.c_void_p]),
     "dvs_raster_forward_views": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.c_int, C.POINTER(Opts), C.c_void_p]),
+    "dvs_raster_forward_cancel_prepared": (C.c_int, [C.c_void_p]),
+    "dvs_raster_forward_views_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.c_int, C.POINTER(Opts), C.c_int64, C.c_int64]),
     "dvs_raster_backward_views": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Splats), C.POINTER(Camera), C.c_int, C.POINTER(Opts),
                                             C.c_void_p, C.POINTER(SplatGrads)]),
     "dvs_get_view_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(FwdState)]),
@@ -152,6 +154,8 @@ _PROTOS = {
     "dvs_mcmc_grow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(McmcSets), C.c_float, C.c_uint32, C.c_int, C.c_void_p, C.c_int]),
     "dvs_mcmc_add_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]),
     "dvs_mcmc_regularize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
+    "dvs_mcmc_add_noise_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]),
+    "dvs_mcmc_regularize_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "dvs_adam_step_groups": (C.c_int, [C.c_void_p, C.POINTER(AdamGroup), C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p,
                                        C.c_int32]),
 }

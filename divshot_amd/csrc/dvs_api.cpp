@@ -106,6 +106,15 @@ struct dvs_ctx {
     bool rows_clean = false;             // gradient rows are all-zero (k_preprocess_bwd re-zeroes what it reads)
     bool rows_pending = false;           // dvs_raster_backward_composite ran, dvs_raster_backward_project has not yet
     int64_t proj_next = 0;               // dvs_raster_backward_project_chunk: the next splat a chunk must start at
+    // dvs_raster_forward_views_prepare: A2 of the NEXT forward already ran for the splats [0, prep_next) with exactly these inputs
+    struct Prep {
+        bool valid = false;
+        int64_t next = 0;
+        int n = 0, V = 0;
+        dvs_splats p{};
+        dvs_opts opts{};
+        dvs_camera cams[DVS_MAX_VIEWS];
+    } prep;
     int bwd_variant = DVS_BWD_TR;        // which A8 kernel (dvs_set_backward_variant; env DVS_BWD_VARIANT at create): the measured winner
     int fwd_variant = DVS_FWD_QUADRANT;  // which A7 kernel (dvs_set_forward_variant; env DVS_FWD_VARIANT at create)
     // stage timing: `timing` = every stage, synchronising per call (profiling iterations); `probe` = hipEvent pairs around the
@@ -285,6 +294,30 @@ void dvs_destroy(dvs_ctx* c) {
     delete c;
 }
 
+// A2 for the splats [first, first + count) of all views (begin: the front end's zeroed state first — the key-range slots and super sums of
+// frontend.hip and the tile ranges behind them, ONE memset)
+static int run_a2(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const dvs_camera* cams, int V, const dvs_opts* opts, int64_t first, int64_t count, bool begin) {
+    const int n = p->n, W = cams[0].width, H = cams[0].height;
+    const int tiles_x = (W + DVS_TILE - 1) / DVS_TILE, tiles_y = (H + DVS_TILE - 1) / DVS_TILE, tiles = tiles_x * tiles_y;
+    const int tight = opts->tile_bounds == DVS_TILES_TIGHT ? 1 : 0;
+    const int rect_fmt = tight ? DVS_FE_RECT_TIGHT : (tiles_x <= 255 && tiles_y <= 255) ? DVS_FE_RECT_U8 : DVS_FE_RECT_U16;
+    DvsCams dcams;
+    for (int v = 0; v < V; ++v) dcams.c[v] = to_dev_cam(cams[v]);
+    if (begin) HIPCHECK(hipMemsetAsync(c->ranges.p, 0, c->fe_zero_bytes + (size_t)tiles * V * 8, st));
+    HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
+                                       opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
+                                       c->depth.as<float>(), c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
+                                       nullptr, opts->shn_layout, rect_fmt == DVS_FE_RECT_U16 ? c->rect.as<uint32_t>() : nullptr,
+                                       rect_fmt == DVS_FE_RECT_TIGHT ? c->rect.as<uint32_t>() : nullptr,
+                                       rect_fmt == DVS_FE_RECT_U8 ? c->rect.as<uint32_t>() : nullptr, fe_kred(c), (int)first, (int)count));
+    return DVS_OK;
+}
+static bool prep_matches(const dvs_ctx* c, const dvs_splats* p, const dvs_camera* cams, int V, const dvs_opts* opts) {
+    const dvs_ctx::Prep& q = c->prep;
+    return q.valid && q.n == p->n && q.V == V && memcmp(&q.p, p, sizeof *p) == 0 && memcmp(&q.opts, opts, sizeof *opts) == 0 &&
+           memcmp(q.cams, cams, sizeof(dvs_camera) * (size_t)V) == 0;
+}
+
 // A2..A7 for the n_views views of a batch (n_views = 1: the single-view API). Per-splat arrays are view-major [view][splat]; the
 // sort value of an element is its global index view * n + splat; tile ids are view * tiles + tile: ONE depth sort, ONE scan, ONE
 // duplication, ONE tile sort and ONE composite launch cover the whole iteration.
@@ -335,15 +368,12 @@ static int forward_views(dvs_ctx* c, hipStream_t st, const dvs_splats* p, const 
     {
         // ---- the segmented front end (frontend.hip): every view is a segment of the sorts, workgroup b works for view b % V ----
         const int rect_fmt = tight ? DVS_FE_RECT_TIGHT : (tiles_x <= 255 && tiles_y <= 255) ? DVS_FE_RECT_U8 : DVS_FE_RECT_U16;
-        // one memset: the key-range slots and super sums of the front end + the tile ranges behind them
-        HIPCHECK(hipMemsetAsync(c->ranges.p, 0, c->fe_zero_bytes + (size_t)tiles * V * 8, st));
+        // A2 — unless dvs_raster_forward_views_prepare already ran it, chunk by chunk, for exactly these inputs (a data-parallel step
+        // projects the next iteration's splats behind the optimizer's chunks while the gradient exchange is still on the links)
+        const bool prepared = prep_matches(c, p, cams, V, opts) && c->prep.next == (int64_t)n;
+        c->prep.valid = false;
         size_t e0 = tm.mark();
-        HIPCHECK(dvs_launch_preprocess_fwd(st, n, p->pos, p->sh0, p->shN, p->opacity, p->scale, p->rot, dcams, V, opts->sh_degree,
-                                           opts->antialias, tiles_x, tiles_y, c->radii.as<int>(), c->splat2d.as<float>(),
-                                           c->depth.as<float>(), c->flags.as<uint32_t>(), c->tiles_touched.as<uint32_t>(), c->key[0].as<uint32_t>(),
-                                           nullptr, opts->shn_layout, rect_fmt == DVS_FE_RECT_U16 ? c->rect.as<uint32_t>() : nullptr,
-                                           rect_fmt == DVS_FE_RECT_TIGHT ? c->rect.as<uint32_t>() : nullptr,
-                                           rect_fmt == DVS_FE_RECT_U8 ? c->rect.as<uint32_t>() : nullptr, fe_kred(c)));
+        if (!prepared) { int r = run_a2(c, st, p, cams, V, opts, 0, n, true); if (r != DVS_OK) return r; }
         size_t e1 = tm.mark(); tm.span("preprocess_fwd", e0, e1);
         if (n > 0) {
             // A5 (low 32 key bits): three range-adaptive passes per view; the culled splats leave in the first
@@ -481,6 +511,39 @@ int dvs_raster_forward_views(dvs_ctx* c, void* stream, const dvs_splats* p, cons
     if (r != DVS_OK) return r;
     HIPCHECK(hipSetDevice(c->device));
     return forward_views(c, (hipStream_t)stream, p, cams, n_views, opts, out_rgb, nullptr, nullptr);
+}
+
+int dvs_raster_forward_cancel_prepared(dvs_ctx* c) {
+    if (!c) { g_last_error = "dvs_raster_forward_cancel_prepared: null context"; return DVS_ERR_INVALID; }
+    c->prep.valid = false;
+    return DVS_OK;
+}
+int dvs_raster_forward_views_prepare(dvs_ctx* c, void* stream, const dvs_splats* p, const dvs_camera* cams, int n_views, const dvs_opts* opts,
+                                     int64_t first, int64_t count) {
+    static float dummy_rgb;                                       // (the argument check wants a non-null image pointer)
+    int r = check_fwd_args(c, p, cams, n_views, opts, &dummy_rgb);
+    if (r != DVS_OK) return r;
+    if (opts->shn_layout != DVS_SHN_TILED) { g_last_error = "dvs_raster_forward_views_prepare: needs the DVS_SHN_TILED layout"; return DVS_ERR_INVALID; }
+    const bool begin = first == 0;
+    if (!begin && !(prep_matches(c, p, cams, n_views, opts) && c->prep.next == first)) {
+        c->prep.valid = false;
+        g_last_error = "dvs_raster_forward_views_prepare: chunks must cover [0, n) in ascending order with the same parameters, cameras and options";
+        return DVS_ERR_STATE;
+    }
+    if (count <= 0 || first < 0 || first + count > p->n || (first % 256) != 0) {
+        c->prep.valid = false;
+        g_last_error = "dvs_raster_forward_views_prepare: bad chunk (each starts at a multiple of 256 and lies inside [0, n))"; return DVS_ERR_INVALID;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    if (begin) {
+        // the state of the previous forward is overwritten from here on: its backward must have been queued already (no backward after this)
+        c->have_fwd = false; c->rows_pending = false;
+        c->prep.valid = true; c->prep.next = 0; c->prep.n = p->n; c->prep.V = n_views; c->prep.p = *p; c->prep.opts = *opts;
+        memcpy(c->prep.cams, cams, sizeof(dvs_camera) * (size_t)n_views);
+    }
+    if ((r = run_a2(c, (hipStream_t)stream, p, cams, n_views, opts, first, count, begin)) != DVS_OK) { c->prep.valid = false; return r; }
+    c->prep.next = first + count;
+    return DVS_OK;
 }
 
 int dvs_get_view_state(dvs_ctx* c, int view, dvs_fwd_state* out) {

@@ -12,7 +12,8 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect /*[n,2]: 4 x u16*/,
                                      uint32_t* rect16 /*DVS_TILES_TIGHT: [n,4] = rectangle + 64-bit tile mask, written instead of rect; null = canonical*/,
                                      uint32_t* rect8 = nullptr /*DVS_FE_RECT_U8: [n] 4 x u8 (minx, miny, width, height) instead of rect*/,
-                                     uint32_t* kred = nullptr /*segmented front end: the views' key ranges [n_views][64][16] (zeroed by the caller); ids may then be null*/);
+                                     uint32_t* kred = nullptr /*segmented front end: the views' key ranges [n_views][64][16] (zeroed by the caller); ids may then be null*/,
+                                     int first = 0, int count = -1 /*splat range of this launch: [first, first + count), count < 0 = up to n*/);
 hipError_t dvs_launch_preprocess_bwd(hipStream_t st, int n, const float* pos, const float* shN, const float* opacity,
                                      const float* scale, const float* rot, const DvsCam& cam, int deg, int antialias,
                                      const int* radii, const uint32_t* flags, float* grad_rows /*[n,12], read then re-zeroed*/,

@@ -212,9 +212,9 @@ k_mcmc_update_src(int n, uint32_t* __restrict__ count, float min_opacity, int la
 }
 
 __global__ void __launch_bounds__(MB)
-k_mcmc_noise(int n, float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot, const float* __restrict__ opacity,
-             float lr, uint32_t seed) {
-    const int i = blockIdx.x * MB + threadIdx.x;
+k_mcmc_noise(int i0, int n /*the splats [i0, n)*/, float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot,
+             const float* __restrict__ opacity, float lr, uint32_t seed) {
+    const int i = i0 + blockIdx.x * MB + threadIdx.x;              // (the random numbers are a function of the GLOBAL index: a range launch draws the same)
     if (i >= n) return;
     const float o = m_sigmoid(opacity[i]);
     const float gate = 1.0f / (1.0f + __expf(100.0f * (o - 0.005f)));          // ~1 for nearly dead splats, ~0 for solid ones
@@ -241,9 +241,9 @@ k_mcmc_noise(int n, float* __restrict__ pos, const float* __restrict__ scale, co
 }
 
 __global__ void __launch_bounds__(MB)
-k_mcmc_regularize(int n, const float* __restrict__ opacity, const float* __restrict__ scale, float* __restrict__ g_opacity,
+k_mcmc_regularize(int i0, int n /*the splats [i0, n)*/, const float* __restrict__ opacity, const float* __restrict__ scale, float* __restrict__ g_opacity,
                   float* __restrict__ g_scale, float wo, float ws) {
-    const int i = blockIdx.x * MB + threadIdx.x;
+    const int i = i0 + blockIdx.x * MB + threadIdx.x;
     if (i >= n) return;
     const float o = m_sigmoid(opacity[i]);
     g_opacity[i] += wo * o * (1.0f - o);                              // d/dlogit of wo * sigmoid(logit)
@@ -297,19 +297,27 @@ int dvs_mcmc_grow(void* stream, int n, int n_new, const dvs_mcmc_sets* sets, flo
     return run_draws((hipStream_t)stream, n, n_new, false, n, sets, min_opacity, seed, shn_layout, scratch, (size_t)capacity);
 }
 
-int dvs_mcmc_add_noise(void* stream, int n, float* pos, const float* scale, const float* rot, const float* opacity, float lr, uint32_t seed) {
-    if (n < 0 || (n > 0 && (!pos || !scale || !rot || !opacity))) return DVS_ERR_INVALID;
-    if (n == 0 || lr == 0.f) return DVS_OK;
-    hipLaunchKernelGGL(k_mcmc_noise, dim3((n + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, n, pos, scale, rot, opacity, lr, seed);
+int dvs_mcmc_add_noise_range(void* stream, int n, int first, int count, float* pos, const float* scale, const float* rot, const float* opacity, float lr,
+                             uint32_t seed) {
+    if (n < 0 || first < 0 || count < 0 || first + count > n || (n > 0 && (!pos || !scale || !rot || !opacity))) return DVS_ERR_INVALID;
+    if (count == 0 || lr == 0.f) return DVS_OK;
+    hipLaunchKernelGGL(k_mcmc_noise, dim3((count + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, first, first + count, pos, scale, rot, opacity, lr, seed);
     return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
 }
+int dvs_mcmc_add_noise(void* stream, int n, float* pos, const float* scale, const float* rot, const float* opacity, float lr, uint32_t seed) {
+    return dvs_mcmc_add_noise_range(stream, n, 0, n, pos, scale, rot, opacity, lr, seed);
+}
 
-int dvs_mcmc_regularize(void* stream, int n, const float* opacity, const float* scale, float* g_opacity, float* g_scale, float opacity_reg,
-                        float scale_reg) {
-    if (n < 0 || (n > 0 && (!opacity || !scale || !g_opacity || !g_scale))) return DVS_ERR_INVALID;
-    if (n == 0) return DVS_OK;
-    hipLaunchKernelGGL(k_mcmc_regularize, dim3((n + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, n, opacity, scale, g_opacity, g_scale,
+int dvs_mcmc_regularize_range(void* stream, int n, int first, int count, const float* opacity, const float* scale, float* g_opacity, float* g_scale,
+                              float opacity_reg, float scale_reg) {
+    if (n < 0 || first < 0 || count < 0 || first + count > n || (n > 0 && (!opacity || !scale || !g_opacity || !g_scale))) return DVS_ERR_INVALID;
+    if (count == 0) return DVS_OK;
+    hipLaunchKernelGGL(k_mcmc_regularize, dim3((count + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, first, first + count, opacity, scale, g_opacity, g_scale,
                        opacity_reg / (float)n, scale_reg / (3.0f * (float)n));
     return hipGetLastError() == hipSuccess ? DVS_OK : DVS_ERR_HIP;
+}
+int dvs_mcmc_regularize(void* stream, int n, const float* opacity, const float* scale, float* g_opacity, float* g_scale, float opacity_reg,
+                        float scale_reg) {
+    return dvs_mcmc_regularize_range(stream, n, 0, n, opacity, scale, g_opacity, g_scale, opacity_reg, scale_reg);
 }
 }

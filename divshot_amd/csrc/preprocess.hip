@@ -80,12 +80,14 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
                  uint4* __restrict__ rect16 /*DVS_TILES_TIGHT: {rectangle, tile mask lo, hi} instead of `rect` (null: canonical rectangles)*/,
                  uint32_t* __restrict__ rect8 /*DVS_FE_RECT_U8: minx | miny << 8 | width << 16 | height << 24 instead of `rect` (null: 16-bit fields)*/,
                  uint32_t* __restrict__ kred /*segmented front end (frontend.hip): [view][64 slots][16 words], word 0 = max(~key), word 1 = max(key)
-                 over the view's visible splats, zeroed by the caller; null = the batch-wide sort of rounds 1-4, which wants `ids`*/) {
+                 over the view's visible splats, zeroed by the caller; null = the batch-wide sort of rounds 1-4, which wants `ids`*/,
+                 int i0, int i1 /*this launch covers the splats [i0, i1): all of them, or one chunk of a data-parallel step that projects the
+                 next iteration's splats chunk by chunk behind the optimizer (dvs_raster_forward_views_prepare); n stays the view-major stride*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PP_BLOCK*45] when deg>0
-    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    const int64_t base = (int64_t)i0 + (int64_t)blockIdx.x * PP_BLOCK;
     const int i = (int)(base + threadIdx.x);
     // issue this lane's own parameter loads first so they are in flight together with the cooperative shN staging
-    const int il = i < n ? i : (n - 1);
+    const int il = i < i1 ? i : (i1 - 1);
     const float in_px = pos[3 * (int64_t)il], in_py = pos[3 * (int64_t)il + 1], in_pz = pos[3 * (int64_t)il + 2];
     const float in_s0 = scale[3 * (int64_t)il], in_s1 = scale[3 * (int64_t)il + 1], in_s2 = scale[3 * (int64_t)il + 2];
     const float4 in_q = reinterpret_cast<const float4*>(rot)[il];
@@ -99,10 +101,10 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
         for (int c = 0; c < 12; ++c) in_q4[c] = c < nchunk ? t4[shn_tiled_f4(il, c)] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (!TILED && deg > 0) {
-        stage_rows_in<45>(shN, lds, base, n);
+        stage_rows_in<45>(shN, lds, base, i1);
         __syncthreads();
     }
-    if (i >= n) return;
+    if (i >= i1) return;
     (void)cams_arg;
     // One lane per splat, all views of the batch: the 236 B of parameters are read once per iteration instead of once per view;
     // the per-view outputs are view-major ([view][splat]: index o), the sort value is the global index.
@@ -261,7 +263,7 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     const float4 rc2 = make_float4(out_rgb[2], out_depth, __int_as_float(out_radius), cull_bound);
     const float4 rc3 = make_float4(cull_det_c, cull_det_a, cull_nb_c, cull_nb_a);
     const int wave_base = (int)base + (int)(threadIdx.x & ~63u);
-    if (wave_base + 64 <= n) {                 // (a whole wave of valid splats: uniform per wave)
+    if (wave_base + 64 <= i1) {                // (a whole wave of valid splats: uniform per wave)
         __shared__ float4 s_rec[PP_BLOCK * 4];
         float4* w = s_rec + (threadIdx.x & ~63u) * 4;           // this wave's 4 KB; wave-local, LDS ops of a wave execute in order
         const int lane = threadIdx.x & 63;
@@ -286,7 +288,7 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
         // the view's key range for the range-adaptive depth sort: one pair of atomics per wave into one of 64 slots (64 B apart)
         uint32_t knm = ~out_key, kmx = out_radius > 0 ? out_key : 0u;         // both are max reductions with identity 0 (culled: ~0xFFFFFFFF = 0)
         uint32_t* slot = kred + ((size_t)view * 64 + (blockIdx.x & 63u)) * 16;
-        if (wave_base + 64 <= n) {
+        if (wave_base + 64 <= i1) {
             // wave64 max in six DPP steps (row_shr 1, 2, 4, 8, row_bcast 15, 31): lane 63 ends with the wave's maximum
 #define A2_DPP_MAX(v, ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false); v = o_ > v ? o_ : v; }
             A2_DPP_MAX(knm, 0x111, 0xF) A2_DPP_MAX(kmx, 0x111, 0xF) A2_DPP_MAX(knm, 0x112, 0xF) A2_DPP_MAX(kmx, 0x112, 0xF)
@@ -1023,13 +1025,15 @@ hipError_t dvs_launch_preprocess_fwd(hipStream_t st, int n, const float* pos, co
                                      int deg, int antialias, int tiles_x, int tiles_y, int* radii, float* splat2d,
                                      float* depth, uint32_t* flags,
                                      uint32_t* tiles_touched, uint32_t* depth_key, uint32_t* ids, int shn_tiled, uint32_t* rect, uint32_t* rect16,
-                                     uint32_t* rect8, uint32_t* kred) {
+                                     uint32_t* rect8, uint32_t* kred, int first, int count) {
     if (n <= 0) return hipSuccess;
-    const int grid = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const int i0 = first < 0 ? 0 : first, i1 = count < 0 ? n : (first + count < n ? first + count : n);
+    if (i1 <= i0) return hipSuccess;
+    const int grid = (i1 - i0 + PP_BLOCK - 1) / PP_BLOCK;
     if (shn_tiled) {
 #define DVS_A2(T, M, LDS) hipLaunchKernelGGL((k_preprocess_fwd<T, M>), dim3(grid), dim3(PP_BLOCK), LDS, st, cams, n_views, n, pos, sh0, shN, opacity, \
                                              scale, rot, deg, antialias, tiles_x, tiles_y, radii, (float4*)splat2d, depth, flags,          \
-                                             tiles_touched, depth_key, ids, (uint2*)rect, (uint4*)rect16, rect8, kred)
+                                             tiles_touched, depth_key, ids, (uint2*)rect, (uint4*)rect16, rect8, kred, i0, i1)
         if (n_views > 1) DVS_A2(true, true, 0); else DVS_A2(true, false, 0);
     } else {
         const size_t lds = deg > 0 ? (size_t)PP_BLOCK * 45 * sizeof(float) : 0;

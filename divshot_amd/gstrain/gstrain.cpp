@@ -98,6 +98,9 @@ struct __attribute__((visibility("hidden"))) GaussianTrainerScene::Impl {     //
     float* d_dcolor_scratch = nullptr;                                       // A9's own copy of the colour gradient (the all-gather reads the early one)
     hipStream_t comm_stream = nullptr; hipEvent_t ev_dcolor = nullptr, ev_bwd = nullptr, ev_comm = nullptr;   // collectives run beside A9
     hipEvent_t ev_gather = nullptr; std::vector<hipEvent_t> ev_chunk;        // all-gather done / A9 chunk k queued (chunked geometry all-reduce)
+    bool pipeline = false;                                                   // DVS_EXCHANGE_PIPELINE=1 (with DVS_A9_CHUNKS > 1): see trainStep
+    std::vector<hipEvent_t> ev_ar;                                           // chunk k's geometry all-reduce has landed (communication stream)
+    std::vector<int> next_ci;                                                // the NEXT iteration's cameras, drawn early for the pipelined step
     int a9_chunks = 1;                                                       // DVS_A9_CHUNKS: splat chunks of A9 whose geometry gradients leave one by one (default 1 until
                                                                              // the chunked exchange has run on real multi-GPU hardware: ADVICE r03; equality with the unchunked
                                                                              // exchange is asserted by tests/test_gpu_multirank.py::test_plugin_two_ranks_exchanges_agree)
@@ -142,6 +145,8 @@ struct __attribute__((visibility("hidden"))) GaussianTrainerScene::Impl {     //
         for (hipEvent_t* e : {&ev_dcolor, &ev_bwd, &ev_comm, &ev_gather}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
         for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
         ev_chunk.clear();
+        for (hipEvent_t e : ev_ar) (void)hipEventDestroy(e);
+        ev_ar.clear();
         if (comm_stream) { (void)hipStreamDestroy(comm_stream); comm_stream = nullptr; }
         if (comm) { dvs_comm_destroy(comm); comm = nullptr; }
         for (void** p : {(void**)&d_grad_accum, (void**)&d_denom, (void**)&d_max_radii, (void**)&d_action, (void**)&d_offsets,
@@ -552,10 +557,14 @@ void GaussianTrainerScene::trainStep() {
     // (vpi = 1: one view per GPU and iteration, as the reference's trainStep renders one camera; vpi = 8 on one GPU: BASELINE config C4)
     const int V = m.vpi;
     std::vector<int> ci_all((size_t)m.world * V, 0);                // every rank knows every rank's cameras: the SH rows are rebuilt from them
-    for (size_t k = 0; k < ci_all.size(); ++k) {
-        m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
-        ci_all[k] = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
-    }
+    auto draw_cameras = [&](std::vector<int>& ci) {
+        for (size_t k = 0; k < ci.size(); ++k) {
+            m.cam_rng ^= m.cam_rng << 13; m.cam_rng ^= m.cam_rng >> 7; m.cam_rng ^= m.cam_rng << 17;
+            ci[k] = m.cfg.singleCamera ? 0 : (int)(m.cam_rng % m.cams.size());
+        }
+    };
+    if (m.next_ci.size() == ci_all.size()) { ci_all = m.next_ci; m.next_ci.clear(); }      // (drawn by the previous, pipelined step: the same stream)
+    else draw_cameras(ci_all);
     const int* ci_mine = &ci_all[(size_t)m.rank * V];
     std::vector<dvs_camera> vcams((size_t)V);
     for (int v = 0; v < V; ++v) vcams[(size_t)v] = m.cams[(size_t)ci_mine[v]];
@@ -609,10 +618,17 @@ void GaussianTrainerScene::trainStep() {
         HIP_OR_THROW(hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking));
         for (hipEvent_t* e : {&m.ev_dcolor, &m.ev_bwd, &m.ev_comm, &m.ev_gather}) HIP_OR_THROW(hipEventCreateWithFlags(e, hipEventDisableTiming));
         if (const char* e = getenv("DVS_A9_CHUNKS")) m.a9_chunks = std::max(1, std::min(64, atoi(e)));
-        m.ev_chunk.resize((size_t)m.a9_chunks);
+        if (const char* e = getenv("DVS_EXCHANGE_PIPELINE")) m.pipeline = e[0] == '1' && m.a9_chunks > 1;
+        m.ev_chunk.resize((size_t)m.a9_chunks); m.ev_ar.resize((size_t)m.a9_chunks);
         for (hipEvent_t& e : m.ev_chunk) HIP_OR_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : m.ev_ar) HIP_OR_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (m.rank == 0 && m.a9_chunks > 1)
+            logf_("gradient exchange: A9 in %d splat chunks, each chunk's geometry all-reduce behind it%s", m.a9_chunks,
+                  m.pipeline ? "; PIPELINED across the iteration boundary: Adam and the next iteration's projection run chunk by chunk as the all-reduces land "
+                               "(DVS_EXCHANGE_PIPELINE=1)" : "");
     }
     bool geom_reduced = false;                  // the geometry gradients already left chunk by chunk behind A9
+    int chunk_per = 0, n_chunks = 0;            // ... in n_chunks chunks of chunk_per splats (the last one shorter)
     // densification statistics of the step's views, summed over the ranks in densify(): per view and visible
     // splat  grad_accum += |abs-grad|, denom += 1, max_radii = max
     const bool want_stats = refining && !mcmc;
@@ -685,8 +701,10 @@ void GaussianTrainerScene::trainStep() {
                 DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad[P_ROT] + 4 * (size_t)first, 4 * (size_t)count));
                 DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.comm_stream, m.d_grad[P_OPA] + (size_t)first, (size_t)count));
                 DVS_OR_THROW(dvs_comm_group_end(m.comm));
+                HIP_OR_THROW(hipEventRecord(m.ev_ar[(size_t)k], m.comm_stream));
             }
             geom_reduced = true;
+            chunk_per = per; n_chunks = k;
         } else {
             DVS_OR_THROW(dvs_raster_backward_project(m.ctx, m.stream, &sp, vcams.data(), &opts, &g));
         }
@@ -742,9 +760,49 @@ void GaussianTrainerScene::trainStep() {
         dvs_adam_group sh_groups[2] = {ag[P_SH0], ag[P_SHN]};
         DVS_OR_THROW(dvs_adam_step_groups(m.stream, sh_groups, 2, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
         sh_adam_done = true;
-        HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_comm, 0));
+        if (!(m.pipeline && geom_reduced)) HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_comm, 0));
     } else if (m.comm) {
         DVS_OR_THROW(dvs_comm_all_reduce_sum_f32(m.comm, m.stream, m.d_grad_flat, m.grad_floats));
+    }
+    const bool refine_now = refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0;
+    const bool reset_now = refining && !mcmc && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0;
+    const bool prune_now = !refining && m.cfg.pruneStrategy > 0 && m.cfg.pruneInterval > 0 && it % m.cfg.pruneInterval == 0;
+    if (m.pipeline && geom_reduced && sh_adam_done) {
+        // PIPELINED exchange (round 6; SURVEY 8(e) "Overlap"; DVS_EXCHANGE_PIPELINE=1, off by default until it has run on real links): the
+        // geometry gradients left in chunks behind A9. Here every chunk is finished as soon as ITS all-reduce has landed — regulariser,
+        // Adam on the four geometry groups, exploration noise, each on the chunk's splat range (all element-wise: bit-identical to the
+        // whole-array calls) — and then the NEXT iteration's projection (A2) of that chunk is queued: A2 is per splat, and the chunk's
+        // parameters are final (the SH groups were stepped above, under the all-reduces). Only the last chunk's all-reduce is exposed;
+        // the all-reduces of the chunks before it run under the Adam / A2 of their predecessors. Iterations that refine, reset or prune
+        // change the parameters after Adam: no early projection there (the next forward projects everything itself).
+        const bool early = !refine_now && !reset_now && !prune_now && it < m.cfg.numIters && !m.sequential_views;
+        std::vector<dvs_camera> ncams;
+        dvs_opts nopts = opts;
+        if (early) {
+            m.next_ci.assign(ci_all.size(), 0);
+            draw_cameras(m.next_ci);
+            ncams.resize((size_t)V);
+            for (int v = 0; v < V; ++v) ncams[(size_t)v] = m.cams[(size_t)m.next_ci[(size_t)m.rank * V + v]];
+            nopts.sh_degree = m.cfg.progressiveTrain ? std::min(m.sh_max, it / 1000) : m.sh_max;       // (what the next trainStep will compute from m.step = it)
+            nopts.accumulate = 0;
+        }
+        for (int k = 0; k < n_chunks; ++k) {
+            const int first = k * chunk_per, count = std::min(chunk_per, m.n - first);
+            HIP_OR_THROW(hipStreamWaitEvent(m.stream, m.ev_ar[(size_t)k], 0));
+            if (mcmc)
+                DVS_OR_THROW(dvs_mcmc_regularize_range(m.stream, m.n, first, count, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
+            dvs_adam_group geo[4] = {ag[P_POS], ag[P_OPA], ag[P_SCALE], ag[P_ROT]};
+            for (dvs_adam_group& q : geo) {
+                const size_t off = (size_t)q.width * (size_t)first;
+                q.param += off; q.grad += off; q.m += off; q.v += off; q.count = (uint64_t)q.width * (uint64_t)count;
+            }
+            DVS_OR_THROW(dvs_adam_step_groups(m.stream, geo, 4, 0.9f, 0.999f, 1e-15f, it, nullptr, count));
+            if (mcmc && m.cfg.noiselr > 0.f)
+                DVS_OR_THROW(dvs_mcmc_add_noise_range(m.stream, m.n, first, count, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
+                                                      m.cfg.noiselr * lr_pos, (uint32_t)it));
+            if (early) DVS_OR_THROW(dvs_raster_forward_views_prepare(m.ctx, m.stream, &sp, ncams.data(), V, &nopts, first, count));
+        }
+        goto after_optimizer;
     }
     if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule): a function of the replicated
                        // parameters, added once (after the exchange) on every rank
@@ -758,10 +816,11 @@ void GaussianTrainerScene::trainStep() {
     if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
         DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
                                         m.cfg.noiselr * lr_pos, (uint32_t)it));
-    if (refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0) { if (mcmc) m.densify_mcmc(it); else m.densify(it); }
-    if (refining && !mcmc && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0)
+after_optimizer:
+    if (refine_now) { if (mcmc) m.densify_mcmc(it); else m.densify(it); }
+    if (reset_now)
         DVS_OR_THROW(dvs_reset_opacity(m.stream, m.n, m.d_param[P_OPA], 0.01f, m.d_m[P_OPA], m.d_v[P_OPA]));
-    if (!refining && m.cfg.pruneStrategy > 0 && m.cfg.pruneInterval > 0 && it % m.cfg.pruneInterval == 0) {
+    if (prune_now) {
         m.prune_light(it);
         pruenIteraions.push_back(it);
     }
@@ -830,6 +889,7 @@ void GaussianTrainerScene::resetGaussian() {
     m.reset_stats();
     m.step = 0; curIteration = 0; pruenIteraions.clear();
     m.host_valid = false;
+    (void)dvs_raster_forward_cancel_prepared(m.ctx);          // (a pipelined step may have projected the next iteration's splats already)
     m.status = TrainingStatus::Training;
     m.t0 = std::chrono::steady_clock::now();
 }

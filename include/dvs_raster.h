@@ -245,6 +245,20 @@ int dvs_raster_forward_views(dvs_ctx* ctx, void* stream, const dvs_splats* param
                              const dvs_opts* opts, float* out_rgb);
 int dvs_raster_backward_views(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cams, int n_views,
                               const dvs_opts* opts, const float* dL_drgb, const dvs_splat_grads* out);
+
+/* A2 (project / preprocess) of the NEXT dvs_raster_forward_views on this context, ahead of it and by splat range — for a data-parallel
+ * trainer that updates its parameters chunk by chunk as the chunks' gradient all-reduces land (SURVEY.md 8(e) "Overlap"): as soon as the
+ * optimizer has stepped the splats [first, first + count) their projection for the next iteration's cameras can run, under the all-reduces
+ * of the chunks behind them. Chunks must cover [0, n) in ascending order, each starting at a multiple of 256, with the same parameters
+ * pointers, cameras and options (DVS_SHN_TILED layout); the first chunk (first = 0) invalidates the previous forward's state — its backward
+ * must have been queued before. A following dvs_raster_forward_views with exactly these arguments then skips its own A2 (bit-identical
+ * outputs: A2 is per splat); with anything else, or after an incomplete sequence, it ignores the preparation and projects everything
+ * itself. Asynchronous, on `stream`. */
+int dvs_raster_forward_views_prepare(dvs_ctx* ctx, void* stream, const dvs_splats* params, const dvs_camera* cams, int n_views,
+                                     const dvs_opts* opts, int64_t first, int64_t count);
+/* Forget a preparation (the caller changed the parameters' CONTENTS behind the same pointers — a reset, a refinement): the next forward
+ * projects everything itself. */
+int dvs_raster_forward_cancel_prepared(dvs_ctx* ctx);
 int dvs_get_view_state(dvs_ctx* ctx, int view, dvs_fwd_state* state);
 
 /* Asynchronous forward. By default dvs_raster_forward synchronises `stream` once (it reads the instance count T to size the sort).

@@ -143,6 +143,12 @@ int dvs_mcmc_grow(void* stream, int n, int n_new, const dvs_mcmc_sets* sets, flo
 int dvs_mcmc_add_noise(void* stream, int n, float* pos, const float* scale, const float* rot, const float* opacity, float lr, uint32_t seed);
 int dvs_mcmc_regularize(void* stream, int n, const float* opacity, const float* scale, float* g_opacity, float* g_scale, float opacity_reg,
                         float scale_reg);
+/* the same two for the splats [first, first + count) of the n (full-array pointers): bit-identical to the whole-array calls — the noise is a
+ * function of the global splat index, the regularisers' means are over n. For a data-parallel step that updates its parameters chunk by chunk. */
+int dvs_mcmc_add_noise_range(void* stream, int n, int first, int count, float* pos, const float* scale, const float* rot, const float* opacity, float lr,
+                             uint32_t seed);
+int dvs_mcmc_regularize_range(void* stream, int n, int first, int count, const float* opacity, const float* scale, float* g_opacity, float* g_scale,
+                              float opacity_reg, float scale_reg);
 
 #ifdef __cplusplus
 }

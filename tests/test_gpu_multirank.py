@@ -297,3 +297,50 @@ def test_plugin_two_ranks_exchanges_agree(gpu_device, tmp_path):
         assert report[tag]["within_1e-4"] > 0.97 and report[tag]["within_1e-3"] > 0.995 and upd < 2e-2, (tag, report[tag])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", "two_rank_plugin.json"), "w"), indent=1)
+
+
+@pytest.mark.parametrize("strategy", ["0", "1"])
+def test_plugin_two_ranks_pipelined_exchange_equals_unpipelined(gpu_device, tmp_path, strategy):
+    """VERDICT r05 item 4 — the exchange pipelined across the iteration boundary in the PRODUCT (DVS_EXCHANGE_PIPELINE=1 with
+    DVS_A9_CHUNKS=4): A9 chunk k -> grouped geometry all-reduce of chunk k -> (MCMC regulariser,) Adam on chunk k (, exploration noise)
+    -> the NEXT iteration's projection (A2) of chunk k through dvs_raster_forward_views_prepare. Every one of those is element-wise or
+    per splat, so the pipelined step computes what the unpipelined chunked one computes. Two ranks over the TCP test backend:
+      (a) 60 iterations without refinement: the two replicas BIT-IDENTICAL; against the unpipelined run of the same job the parameters
+          agree as two runs of ANY configuration do (the composite backward's fp32 atomics are not bit-reproducible run to run — the bars
+          of test_plugin_two_ranks_exchanges_agree: 97 % of the elements within 1e-4, the update within 2e-2);
+      (b) 230 iterations across refinements (ADC with an opacity reset / MCMC relocation + growth with noise), i.e. across iterations
+          where the early projection must NOT happen because the parameters change after Adam: replicas bit-identical, the same
+          refinement schedule and splat counts as the unpipelined run (within the handful that threshold decisions on differently
+          ordered sums move)."""
+    import re, numpy as np
+    base = {"DVS_EXCHANGE": "factorised", "DVS_A9_CHUNKS": "4"}
+    # (a)
+    args = ["--inputPath", "synthetic:N=20000,W=256,H=192,cams=6,sh=2,seed=22", "--maxIteration", "60", "--densifyStrategy", strategy,
+            "--warmupLength", "100000", "--packLevel", "0"]
+    out0, _ = _plugin_run(tmp_path, "zero" + strategy, args + ["--maxIteration", "0"], 1)
+    init = _read_ply_rows(out0 + "_0.ply")
+    outp, resp = _plugin_run(tmp_path, "pa" + strategy, args, 2, dict(base, DVS_EXCHANGE_PIPELINE="1"))
+    outu, resu = _plugin_run(tmp_path, "ua" + strategy, args, 2, base)
+    assert "PIPELINED across the iteration boundary" in resp[0][2] and "PIPELINED" not in resu[0][2]
+    assert open(outp + "_60.ply", "rb").read() == open(outp + "_60.ply.rank1", "rb").read(), "pipelined: the two replicas differ"
+    got, ref = _read_ply_rows(outp + "_60.ply"), _read_ply_rows(outu + "_60.ply")
+    assert got.shape == ref.shape and np.abs(ref - init).max() > 1e-3
+    upd = np.linalg.norm(got - ref) / np.linalg.norm(ref - init)
+    rep = {"within_1e-4": _frac_within(got, ref, 1e-4), "within_1e-3": _frac_within(got, ref, 1e-3), "rel_l2_vs_update": float(upd)}
+    assert rep["within_1e-4"] > 0.97 and rep["within_1e-3"] > 0.995 and upd < 2e-2, rep
+    # (b)
+    args = ["--inputPath", "synthetic:N=20000,W=256,H=192,cams=6,sh=2,seed=23", "--maxIteration", "230", "--densifyStrategy", strategy,
+            "--warmupLength", "50", "--refineEvery", "100", "--refineStopIter", "320", "--resetAlphaEvery", "150", "--growGrad2d", "0.00004"]
+    outp, resp = _plugin_run(tmp_path, "pb" + strategy, args, 2, dict(base, DVS_EXCHANGE_PIPELINE="1"))
+    outu, resu = _plugin_run(tmp_path, "ub" + strategy, args, 2, base)
+    pa, pb = open(outp + "_230.ply", "rb").read(), open(outp + "_230.ply.rank1", "rb").read()
+    assert len(pa) > 20000 * 236 // 2 and pa == pb, "pipelined across refinements: the two replicas differ"
+    pat = r"densify @(\d+): (\d+) -> (\d+) splats" if strategy == "0" else r"mcmc @(\d+): (\d+) -> (\d+) splats"
+    sp_ = [(int(a), int(c)) for a, _, c in re.findall(pat, resp[0][2])]
+    su_ = [(int(a), int(c)) for a, _, c in re.findall(pat, resu[0][2])]
+    assert [a for a, _ in sp_] == [a for a, _ in su_] == [100, 200] and sp_[-1][1] != 20000, (sp_, su_)
+    for (_, np_), (_, nu_) in zip(sp_, su_):
+        assert abs(np_ - nu_) <= max(3, 0.003 * nu_), (sp_, su_)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"strategy": strategy, "no_refinement_60_iterations": rep, "refinements": {"pipelined": sp_, "unpipelined": su_}},
+              open(os.path.join(ROOT, "gpurun_out", f"two_rank_pipelined_{strategy}.json"), "w"), indent=1)

@@ -1033,6 +1033,73 @@ def test_fused_sh_rows_equal_the_two_kernel_form(gpu_device):
         r.close()
 
 
+def test_forward_prepared_in_chunks_equals_forward(gpu_device):
+    """dvs_raster_forward_views_prepare (round 6): A2 of the next forward run ahead of it, by splat range — what a data-parallel step does
+    behind its optimizer chunks. A forward after a complete, matching preparation skips its own A2 and is BIT-identical (images, every
+    saved array, gradients of a following backward are those of the plain forward); a preparation that is incomplete, out of order, for
+    other cameras / options, or cancelled is ignored (and refused where the API can tell)."""
+    import torch
+    from divshot_amd.raster import Rasterizer, params_to_device
+    from divshot_amd import _lib as _l
+    n, W, H, V = 6007, 208, 120, 3
+    spec = dv.make_spec(n, W, H, sh_degree=3, n_cams=4, seed=61)
+    P = dv.synth_splats(spec)
+    cams = [dv.synth_camera(spec, i + 1) for i in range(V)]
+    r = Rasterizer(0, max_splats=n, max_w=W, max_h=H, max_views=V)
+    Pd = params_to_device(P, r.tdev)
+    Pd["shN"] = r.shn_relayout(Pd["shN"], n, to_tiled=True)
+    ref = r.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True).clone()
+    ref_saved = [r.view_saved(v) for v in range(V)]
+    dL = torch.rand(ref.shape, device=r.tdev, generator=torch.Generator(device=r.tdev).manual_seed(5)) - 0.5
+    g_ref = {k: t.clone() for k, t in r.backward_views(dL.contiguous()).items()}
+    sp = r._splats(Pd, tiled=True)
+    carr = (_l.Camera * V)(*cams)
+    opts = _l.Opts(); opts.sh_degree = 3; opts.absgrad = 1; opts.shn_layout = 1
+    def prepare(first, count, cam_arr=carr, o=opts):
+        return dv.lib.dvs_raster_forward_views_prepare(r.ctx, None, C.byref(sp), cam_arr, V, C.byref(o), first, count)
+    torch.cuda.synchronize()
+    # complete preparation in three ragged chunks -> the forward is the same forward
+    for first, count in ((0, 2048), (2048, 2560), (4608, n - 4608)):
+        assert prepare(first, count) == 0, dv.lib.dvs_last_error()
+    poison = torch.full_like(Pd["pos"], float("nan"))          # if the forward did run its own A2 now, it would see these positions
+    good = Pd["pos"].clone()
+    torch.cuda.synchronize()
+    Pd["pos"].copy_(poison); torch.cuda.synchronize()
+    img = r.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True)
+    torch.cuda.synchronize()
+    Pd["pos"].copy_(good); torch.cuda.synchronize()
+    assert torch.equal(img, ref), "the prepared forward differs (or ran its own A2)"
+    for v in range(V):
+        sv = r.view_saved(v)
+        for k in ("radii", "flags", "tiles_touched", "vals", "ranges", "n_contrib"):
+            np.testing.assert_array_equal(sv[k], ref_saved[v][k], err_msg=f"view {v} {k}")
+        for k in ("mean2d", "depth", "conic_opacity", "rgb", "final_T"):
+            assert np.array_equal(sv[k].view(np.uint32), ref_saved[v][k].view(np.uint32)), (v, k)
+    g = r.backward_views(dL.contiguous())
+    for k in KEYS:
+        m, worst = rel_close(g[k].cpu().numpy(), g_ref[k].cpu().numpy(), 1e-4, 2e-6)          # (fp32 atomics in A8: not bit-reproducible)
+        assert m.all(), (k, worst)
+    # the preparation is used once: the next forward projects by itself again (NaN positions now cull everything)
+    Pd["pos"].copy_(poison); torch.cuda.synchronize()
+    img_nan = r.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True)
+    torch.cuda.synchronize()
+    Pd["pos"].copy_(good); torch.cuda.synchronize()
+    assert r.num_rendered == 0 and not torch.equal(img_nan, ref)
+    # incomplete / cancelled / mismatching preparations are ignored; out-of-order chunks are refused
+    assert prepare(0, 2048) == 0
+    assert torch.equal(r.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True), ref)             # incomplete
+    assert prepare(0, 2048) == 0 and prepare(4096, 512) != 0 and b"ascending" in dv.lib.dvs_last_error()        # a gap
+    assert prepare(0, n) == 0 and dv.lib.dvs_raster_forward_cancel_prepared(r.ctx) == 0
+    Pd["pos"].copy_(poison); torch.cuda.synchronize()
+    assert r.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True) is not None and r.num_rendered == 0        # cancelled: own A2 saw the NaNs
+    Pd["pos"].copy_(good); torch.cuda.synchronize()
+    other = (_l.Camera * V)(*[dv.synth_camera(spec, i) for i in range(V)])
+    assert prepare(0, n, cam_arr=other) == 0                                                                      # prepared for OTHER cameras
+    assert torch.equal(r.forward_views(Pd, cams, sh_degree=3, absgrad=True, shn_tiled=True), ref)
+    assert prepare(100, 256) != 0 and prepare(0, 0) != 0                                                          # not a multiple of 256 / empty
+    r.close()
+
+
 def test_live_lists_give_the_same_gradients(gpu_device):
     """dvs_set_live_lists: the "tr" backward over the forward's compacted lists (entries that reach their tile) against the same
     kernel over the full lists — one view and a 3-view pass, a scene with many entries that miss their tiles (small, faint splats) and
