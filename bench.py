@@ -171,12 +171,46 @@ def scaling_model(n, world, views_per_rank, per_rank_compute_ms, measured_ms_per
     exposed = t_reduce + max(0.0, t_gather - a9_ms)
     compute = max(per_rank_compute_ms)
     step = compute + exposed
+    # Second column (round 6): the PRODUCT's iteration (libgstrain's train_step = this raster step + the fused Adam) with the exchange
+    # pipelined across the iteration boundary (DVS_EXCHANGE_PIPELINE=1, k = 4 A9 chunks); bench.py's step has no optimizer to hide anything
+    # under, so this is not what the line measures. A small timeline, t = 0 at the start of A9 (the colour all-gather starts there):
+    #   compute stream: A9 chunk j done at j * a9 / k; SH rebuild + SH Adam (0.25 ms per 10^6 splats: 192 of the 236 B) once the gather has
+    #                   landed; then per chunk j, once ITS all-reduce has landed: geometry Adam + the next iteration's A2 of the chunk
+    #                   ((0.06 + 0.086 * views) ms per 10^6 splats, / k)
+    #   communication stream (serial): the gather, then all-reduce j (t_reduce / k + latency) as soon as A9 chunk j is done
+    # exposed = end of the last chunk's work - what the same work takes without any communication.
+    k = 4
+    scale = n / 1e6
+    w_sh, w_geo = 0.25 * scale, (0.06 + 0.086 * views_per_rank) * scale
+
+    def product_exposed(chunks):
+        t_chunk = t_reduce / chunks + lat_ms
+        comm_free, ar_done = t_gather, []
+        for j in range(1, chunks + 1):
+            start = max(a9_ms * j / chunks, comm_free)
+            comm_free = start + t_chunk
+            ar_done.append(comm_free)
+        t = max(a9_ms, t_gather) + w_sh
+        if chunks == 1 or True:
+            for j in range(chunks):
+                t = max(t, ar_done[j]) + w_geo / chunks
+        return t - (a9_ms + w_sh + w_geo)
+    exposed_u, exposed_p = product_exposed(1), product_exposed(k)
+    optimizer_ms = (0.22 + 0.06) * scale
+    step_u, step_p = compute + optimizer_ms + exposed_u, compute + optimizer_ms + exposed_p
     return {"assumptions": {"link_GBps_per_direction": 64, "latency_us_per_collective": 30, "a9_ms_per_local_view": 0.1,
                             "links_driven": world - 1, "exchange": "factorised, direct reduce-scatter + all-gather on every peer link"},
             "all_gather_ms": t_gather, "all_reduce_ms": t_reduce, "predicted_exposed_exchange_ms": exposed,
             "measured_per_rank_compute_ms_max": compute, "predicted_ms_per_step": step,
             "predicted_views_per_s": world * views_per_rank / (step * 1e-3),
-            "measured_ms_per_step": measured_ms_per_step, "measured_over_predicted": measured_ms_per_step / step}
+            "measured_ms_per_step": measured_ms_per_step, "measured_over_predicted": measured_ms_per_step / step,
+            "product_iteration_model": {
+                "note": "libgstrain's train_step = this raster step + the optimizer (fused Adam, 0.28 ms per 10^6 splats); NOT what this line measures. "
+                        "unpipelined: one geometry all-reduce behind A9, SH rebuild + SH Adam under it; pipelined (DVS_EXCHANGE_PIPELINE=1, 4 chunks): A9 "
+                        "chunk -> all-reduce chunk -> geometry Adam chunk -> next iteration's A2 chunk. A model until a multi-GPU run exists.",
+                "optimizer_ms": optimizer_ms, "unpipelined_exposed_ms": exposed_u, "unpipelined_ms_per_iteration": step_u,
+                "unpipelined_views_per_s": world * views_per_rank / (step_u * 1e-3), "pipelined_chunks": k, "pipelined_exposed_ms": exposed_p,
+                "pipelined_ms_per_iteration": step_p, "pipelined_views_per_s": world * views_per_rank / (step_p * 1e-3)}}
 
 
 def watchdog_seconds():
