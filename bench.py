@@ -792,7 +792,7 @@ def main():
                                      # SQ_ACTIVE_INST_VALU in 4-cycle quads over all SIMDs against SIMDs x busy cycles. The two counters come
                                      # from different blocks (SQ per SIMD, GRBM per XCD) and the ratio lands a few per cent above 1 when the
                                      # vector ALUs never idle: reported as a fraction capped at 1, with the raw ratio beside it
-                                     "busy_fraction_at_measured_clock": min(1.0, raw), "active_quads_x4_over_simd_cycles_raw": raw,
+                                     "active_quads_x4_over_simd_cycles_raw": raw,                 # (the capped "busy fraction" of rounds 4-5 is gone: see roofline.secondary)
                                      "note": "an upper bound on how busy the vector ALUs are, not proof that issue is what limits the kernel: the "
                                              "round-4 ablations (profiles/r04_a8_ablation.txt) show the per-batch latency chain (staging gather, "
                                              "table read-add-write passes) costs more than the arithmetic"})
@@ -807,6 +807,27 @@ def main():
                         "region (dvs_enable_kernel_probe)" if in_step_ms else "per-stage hipEvent timing, one view at a time"), "valu_issue": valu,
                         "note": "k_render_bwd is VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ kernel duration, profiles/r*_pmc_sq.txt), "
                                 "so its HBM fraction is low by construction; see DESIGN.md section 5"}
+            # the ceiling the composite kernels are actually against (SURVEY 8(d) "secondary ceilings"): vector-instruction
+            # issue = sum over instruction classes of (dynamic count x measured issue cost) / (kernel cycles x SIMDs), tools/valu_ceiling.py
+            try:
+                import glob
+                vfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_ceiling.json")))[-1]
+                vj = json.load(open(vfile))
+                sec = {}
+                for kn_, rec_ in vj["kernels"].items():
+                    sec[kn_] = {"frac": rec_["frac_of_valu_issue_ceiling"], "valu_wave_instructions_per_launch": rec_["valu_wave_instructions_per_launch"],
+                                "issue_cycles_per_launch": rec_["issue_cycles_per_launch"], "kernel_cycles_per_launch": rec_["kernel_cycles_per_launch"],
+                                "clock_GHz": rec_["clock_GHz"]}
+                dom_key = next((k_ for k_ in sec if k_.startswith(kern.rstrip("<"))), None)
+                roofline["secondary"] = {"bound": "valu_issue", "frac": sec[dom_key]["frac"] if dom_key else None, "kernel": dom_key, "kernels": sec,
+                                         "source": "profiles/" + os.path.basename(vfile),
+                                         "definition": "sum over instruction classes (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, _INT32, _CVT, rest) of count per launch x issue "
+                                                       "cost in SIMD cycles (tools/ubench/valu_cost at its measured clock) / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs); the "
+                                                       "'rest' class is priced with the kernel's static mix; accounting uncertainty ~ +-10 %: a value near 1 means the "
+                                                       "kernel is at the vector-issue ceiling of its instruction mix",
+                                         "collected_on_these_kernels": vj.get("kernel_source_sha16") == kernel_source_sha()}
+            except Exception:      # noqa: BLE001
+                pass
         # the same recomputation for every stage of the step's multi-view pass: algorithmic bytes per launch / measured stage time
         if roofline is not None and batch_stage_ms:
             kern_names = {"preprocess_fwd": "k_preprocess_fwd", "depth_sort": "k_seg_hist/rowscan/scatter x3 (depth bits, range-adaptive digits, per view)",
@@ -928,6 +949,18 @@ def main():
                                    "fwd_per_s": inter / (stage_ms["render_fwd"] * 1e-3) if "render_fwd" in stage_ms else None,
                                    "bwd_per_s": inter / (stage_ms["render_bwd"] * 1e-3) if "render_bwd" in stage_ms else None,
                                    "note": "upper bound on evaluated pairs: per-8x8-quadrant culling skips ~2/3 of them (DESIGN.md section 5)"}
+            if args.workload == "C3":
+                # against the pairs the kernels actually EVALUATE, from the committed launch statistics of this scene:
+                # A7 visits a (live entry, 8x8 quadrant) pair with 64 lanes — 72.0 % of the 3.03 M entries per view are live and a live entry
+                # reaches 1.87 quadrants (profiles/r05_quadrant_stats.json): 4.08 M visits = 261 M evaluated pairs per view (before early
+                # termination of saturated quadrants); A8 walks (entry, 4x4 block) pairs with 16 lanes: 74.9 M pairs per 8-view launch
+                # (profiles/r03_a8_probe.txt, TR_STATS) = 149.8 M evaluated pairs per view, 85.4 M of them contributing.
+                ev_f, ev_b = 0.720 * 3032201 * 1.87 * 64, 74.9e6 * 16 / 8
+                rec["interactions"]["evaluated_pairs_per_view"] = {"fwd": ev_f, "bwd": ev_b, "bwd_contributing": 85.4e6,
+                                                                   "source": "profiles/r05_quadrant_stats.json, profiles/r03_a8_probe.txt (launch statistics of this scene)"}
+                for key_, ev_ in (("fwd", ev_f), ("bwd", ev_b)):
+                    ms_ = batch_stage_ms.get("render_" + key_) if batch_stage_ms else None
+                    rec["interactions"]["evaluated_" + key_ + "_per_s"] = (ev_ * G / (ms_ * 1e-3)) if ms_ else None
         except Exception as e:      # noqa: BLE001
             rec["interactions"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:

@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#define REP 200
+#ifndef REP
+#define REP 2000        /* long enough (0.3 - 1 ms per kernel) that launch ramp-up is < 2 % of the measurement (round 6; was 200) */
+#endif
 #define UN 16
 #define BODY(ASM)                                                                                   \
     for (int r = 0; r < REP; ++r) {                                                                 \
@@ -37,6 +39,12 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, long long
     if (OP == 17) { BODY("v_max_f32 %0, %0, %1") }
     if (OP == 18) { BODY("v_cmp_lt_f32 vcc, %0, %1") }
     if (OP == 19) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; u += 2) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[u]) : "v"(y[u]), "v"(x[u + 1])); asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(y[u + 1]) : "v"(y[u]), "v"(x[u + 1])); } } }
+    if (OP == 25) { BODY("v_add_u32 %0, %0, %1") }
+    if (OP == 26) { BODY("v_mov_b32 %0, %1") }
+    if (OP == 27) { BODY("v_lshlrev_b32 %0, 3, %1") }
+    if (OP == 28) { BODY("v_mad_u32_u24 %0, %0, %1, %1") }
+    if (OP == 29) { BODY("v_cvt_f32_u32 %0, %1") }
+    if (OP == 30) { BODY("v_and_b32 %0, %0, %1") }
     unsigned long long sm[UN];
     if (OP >= 20) for (int u = 0; u < UN; ++u) sm[u] = __builtin_amdgcn_readfirstlane(blockIdx.x + u) | 0x100000000ull;
     if (OP == 20) { for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int u = 0; u < UN; ++u) { asm volatile("s_and_b64 %0, %0, %1" : "+s"(sm[u]) : "s"(sm[(u + 1) % UN]) : "scc"); } } }
@@ -98,5 +106,7 @@ int main(int argc, char** argv) {
     run("v_cndmask_b32 sgpr mask", k<14>, out, cyc, blocks); run("v_add_f32", k<15>, out, cyc, blocks); run("v_fmac_f32", k<16>, out, cyc, blocks);
     run("v_max_f32", k<17>, out, cyc, blocks); run("v_cmp_lt_f32 vcc", k<18>, out, cyc, blocks); run("v_fma_f32 3 distinct src", k<19>, out, cyc, blocks);
     run("v_pk_fma_f32", kpk<0>, out, cyc, blocks); run("v_pk_mul_f32", kpk<1>, out, cyc, blocks);
+    run("v_add_u32", k<25>, out, cyc, blocks); run("v_mov_b32", k<26>, out, cyc, blocks); run("v_lshlrev_b32", k<27>, out, cyc, blocks);
+    run("v_mad_u32_u24", k<28>, out, cyc, blocks); run("v_cvt_f32_u32", k<29>, out, cyc, blocks); run("v_and_b32", k<30>, out, cyc, blocks);
     return 0;
 }
