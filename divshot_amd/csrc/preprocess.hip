@@ -95,10 +95,25 @@ k_preprocess_fwd(DvsCams cams_arg /* MUST stay the first parameter: read through
     const float in_dc0 = sh0[3 * (int64_t)il], in_dc1 = sh0[3 * (int64_t)il + 1], in_dc2 = sh0[3 * (int64_t)il + 2];
     float4 in_q4[12];                         // TILED: the splat's twelve float4 chunks, requested up front with everything else
     if (TILED) {
+        // One straight run of loads per SH degree (12 / 6 / 3 / 0 chunks), nothing conditional between them. (Through round 5 every chunk had
+        // its own `c < nchunk` test: the compiler turned that into a branch per chunk with a register copy — and an s_waitcnt vmcnt(0) — behind
+        // the second one, i.e. every wave waited for its first seven loads before it requested the other ten chunks. Removing that did NOT
+        // change the kernel's time — 85 us for one view at C3 either way, same-box A/B — so the dependent round trip was not what bounds it;
+        // the straight form stays because it is the simpler code.)
         const float4* t4 = reinterpret_cast<const float4*>(shN);
-        const int nchunk = (((deg + 1) * (deg + 1) - 1) * 3 + 3) >> 2;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < 12; ++c) in_q4[c] = c < nchunk ? t4[shn_tiled_f4(il, c)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < 12; ++c) in_q4[c] = z4;
+        if (deg >= 3) {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) in_q4[c] = t4[shn_tiled_f4(il, c)];
+        } else if (deg == 2) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) in_q4[c] = t4[shn_tiled_f4(il, c)];
+        } else if (deg == 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) in_q4[c] = t4[shn_tiled_f4(il, c)];
+        }
     }
     if (!TILED && deg > 0) {
         stage_rows_in<45>(shN, lds, base, i1);
