@@ -767,7 +767,8 @@ void GaussianTrainerScene::trainStep() {
     const bool refine_now = refining && it > m.cfg.warmupLength && m.cfg.refineEvery > 0 && it % m.cfg.refineEvery == 0;
     const bool reset_now = refining && !mcmc && m.cfg.resetAlphaEvery > 0 && it % m.cfg.resetAlphaEvery == 0;
     const bool prune_now = !refining && m.cfg.pruneStrategy > 0 && m.cfg.pruneInterval > 0 && it % m.cfg.pruneInterval == 0;
-    if (m.pipeline && geom_reduced && sh_adam_done) {
+    const bool pipelined_tail = m.pipeline && geom_reduced && sh_adam_done;
+    if (pipelined_tail) {
         // PIPELINED exchange (round 6; SURVEY 8(e) "Overlap"; DVS_EXCHANGE_PIPELINE=1, off by default until it has run on real links): the
         // geometry gradients left in chunks behind A9. Here every chunk is finished as soon as ITS all-reduce has landed — regulariser,
         // Adam on the four geometry groups, exploration noise, each on the chunk's splat range (all element-wise: bit-identical to the
@@ -802,21 +803,20 @@ void GaussianTrainerScene::trainStep() {
                                                       m.cfg.noiselr * lr_pos, (uint32_t)it));
             if (early) DVS_OR_THROW(dvs_raster_forward_views_prepare(m.ctx, m.stream, &sp, ncams.data(), V, &nopts, first, count));
         }
-        goto after_optimizer;
-    }
-    if (mcmc)          // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule): a function of the replicated
-                       // parameters, added once (after the exchange) on every rank
-        DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
-    if (sh_adam_done) {
-        dvs_adam_group geo_groups[4] = {ag[P_POS], ag[P_OPA], ag[P_SCALE], ag[P_ROT]};
-        DVS_OR_THROW(dvs_adam_step_groups(m.stream, geo_groups, 4, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
     } else {
-        DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
+        if (mcmc)      // opacity and scale regularisers of the MCMC strategy (0.01 each in the published rule): a function of the replicated
+                       // parameters, added once (after the exchange) on every rank
+            DVS_OR_THROW(dvs_mcmc_regularize(m.stream, m.n, m.d_param[P_OPA], m.d_param[P_SCALE], m.d_grad[P_OPA], m.d_grad[P_SCALE], 0.01f, 0.01f));
+        if (sh_adam_done) {
+            dvs_adam_group geo_groups[4] = {ag[P_POS], ag[P_OPA], ag[P_SCALE], ag[P_ROT]};
+            DVS_OR_THROW(dvs_adam_step_groups(m.stream, geo_groups, 4, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
+        } else {
+            DVS_OR_THROW(dvs_adam_step_groups(m.stream, ag, 6, 0.9f, 0.999f, 1e-15f, it, adam_gate, m.n));
+        }
+        if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
+            DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
+                                            m.cfg.noiselr * lr_pos, (uint32_t)it));
     }
-    if (mcmc && m.cfg.noiselr > 0.f)      // exploration noise, scaled by the position learning rate (`noiselr`, gs_train.cpp:97)
-        DVS_OR_THROW(dvs_mcmc_add_noise(m.stream, m.n, m.d_param[P_POS], m.d_param[P_SCALE], m.d_param[P_ROT], m.d_param[P_OPA],
-                                        m.cfg.noiselr * lr_pos, (uint32_t)it));
-after_optimizer:
     if (refine_now) { if (mcmc) m.densify_mcmc(it); else m.densify(it); }
     if (reset_now)
         DVS_OR_THROW(dvs_reset_opacity(m.stream, m.n, m.d_param[P_OPA], 0.01f, m.d_m[P_OPA], m.d_v[P_OPA]));
