@@ -87,13 +87,13 @@ def read_clocks(dev_index=0):
 
 
 def kernel_source_sha():
-    """sha256 (16 hex digits) over divshot_amd/csrc/*.{hip,h,cpp} — the same digest tools/make_traffic_json.py stores in profiles/r*_traffic.json, so
+    """sha256 (16 hex digits) over divshot_amd/csrc/*.{hip,h} (the device code and its headers) — the same digest tools/make_traffic_json.py stores in profiles/r*_traffic.json, so
     that the line can say whether the committed PMC counters were collected on the kernels it is timing (stale counters silently
     divided by fresh times)."""
     import glob, hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "divshot_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/dvs_raster.h"
@@ -255,6 +256,8 @@ dvs_ctx* dvs_create_views(int device, size_t max_splats, int max_w, int max_h, i
     {   // how the sorts' scatters rank inside a wave (frontend.hip): returning LDS adds, if this device serves the lanes of one address in
         // lane order — probed once per process and device, on the device; DVS_FE_RANK=ballot keeps the multisplit of rounds 2-5
         static int probed[64];                    // 0 unknown, 1 lane-ordered, 2 not
+        static std::mutex probe_mutex;            // (hosts create scenes from worker threads: editor.cpp:2030)
+        std::lock_guard<std::mutex> probe_lock(probe_mutex);
         const char* mode = getenv("DVS_FE_RANK");
         if (mode && mode[0] == 'b') c->fe_rank_atomic = 0;
         else {

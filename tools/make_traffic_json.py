@@ -14,11 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_source_sha():
-    """sha256 over the kernel sources the counters were collected on (divshot_amd/csrc: *.hip, *.h, *.cpp, sorted by name) — bench.py
+    """sha256 over the kernel sources the counters were collected on (divshot_amd/csrc: *.hip and *.h — the device code and its headers — sorted by name) — bench.py
     recomputes it and says whether the committed counters still belong to the code it is timing."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.h")) +
-                    glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.cpp"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "divshot_amd", "csrc", "*.h"))):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
