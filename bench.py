@@ -833,7 +833,8 @@ def main():
             kern_names = {"preprocess_fwd": "k_preprocess_fwd", "depth_sort": "k_seg_hist/rowscan/scatter x3 (depth bits, range-adaptive digits, per view)",
                           "tile_scan": "k_seg_blocksum + k_seg_totals", "duplicate": "k_seg_duplicate",
                           "tile_sort": "k_seg_hist/rowscan/scatter x2 (tile bits, per view; the last pass also builds the tile ranges)", "tile_ranges": "(fused into the tile sort's last pass)",
-                          "render_fwd": "k_render_fwd", "render_bwd": roofline["kernel"], "preprocess_bwd": "k_preprocess_bwd_views + k_sh_grad_combine"}
+                          "render_fwd": "k_render_fwd", "render_bwd": roofline["kernel"],
+                          "preprocess_bwd": "k_preprocess_bwd_views<.., FUSE_SH> (one GPU: the SH rows are built in its epilogue; with N > 1 it emits per-view colour gradients and k_sh_grad_combine follows the all-gather)"}
             # bytes the PMC passes saw per step, by stage (profiles/r*_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) KB per launch x launches per
             # step, summed over the stage's kernels). The two sorts share their kernels: their counter bytes exist for "sort_total" only.
             stage_kernels = {"preprocess_fwd": ("k_preprocess_fwd",), "tile_scan": ("k_seg_blocksum", "k_seg_totals", "k_tile_blocksum", "k_tile_scan_blocks"),
@@ -870,7 +871,9 @@ def main():
                     if stg == "preprocess_fwd":
                         launch_bytes = (44 + B_sh_) * n + 112 * n * G                       # + 64-B record, radii / depth / flags / rect / key / id per (view, splat)
                     else:
-                        launch_bytes = (48 + 12 + 12) * n * G + (44 + B_sh_) * n + 44 * n + 12 * n + B_sh_ * n   # rows in, dcolor out + in; params; geometry + SH gradients out
+                        # rows in (+ re-zeroed: counted once, as SURVEY's formula does); params; geometry + SH gradients out. One GPU (round 6): no
+                        # per-view colour gradients leave the kernel; with N > 1 they are written and re-read by the rebuild (12 + 12 B per view and splat)
+                        launch_bytes = (48 + (0 if world == 1 else 24)) * n * G + (44 + B_sh_) * n + 44 * n + 12 * n + B_sh_ * n
                     ent["algorithmic_bytes_note"] = "per-launch bytes of the multi-view pass (parameters once); SURVEY's per-view figure x views is in algorithmic_bytes"
                     ent["launch_bytes"] = launch_bytes
                 if launch_bytes:
